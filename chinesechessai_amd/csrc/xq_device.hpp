@@ -1,0 +1,539 @@
+// xq_device.hpp — wave-cooperative Xiangqi rules for gfx950 (CDNA4, wave64).
+//
+// One 64-lane wavefront owns one game.  The 10x9 board lives as 90 signed bytes in LDS for the
+// duration of a kernel (nibble-packed, 48 B, in HBM); occupancy is held as wave-uniform 90-bit
+// bitboards produced by __ballot (row-major and column-major), so that ray scans, "pieces
+// between" counts and the legality filter are a handful of bit operations per lane instead of
+// board walks.  Nothing here is a translation of the reference's Python: the behaviour
+// (SURVEY.md Appendix A quirks included) is the contract, checked bit-for-bit against the oracle.
+//
+// Reference behaviour restated: chess_env.py:76-121 (legal moves, order), :123-251 (generators),
+// :431-548 (suicide filter / kings facing / in-check), :253-406 (make_move), :683-737 (shaping).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace xq {
+
+enum : int { KING = 1, ADVISOR = 2, BISHOP = 3, KNIGHT = 4, ROOK = 5, CANNON = 6, PAWN = 7 };
+enum : int { WINNER_NONE = 2, NO_KING = -1, MAXM = 128 };
+enum : int { R_NONE = 0, R_KING_CAPTURED = 1, R_CHECKMATE = 2, R_REPETITION = 3, R_FIFTY = 4,
+             R_STALEMATE = 5, R_PERP_CHECK = 6, R_PERP_CHASE = 7, R_MOVE_CAP = 8 };
+
+#define XQ_LANE ((int)(threadIdx.x & 63))
+
+__device__ __forceinline__ void wave_sync() { __syncthreads(); }   // block == one wave
+
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// ---------------------------------------------------------------- 90-bit bitboards
+struct BB {            // bit s of (lo,hi): lo = squares 0..63, hi = squares 64..89
+    uint64_t lo, hi;
+};
+
+__device__ __forceinline__ int bb_test(const BB &b, int s)
+{
+    return (int)(((s < 64) ? (b.lo >> s) : (b.hi >> (s - 64))) & 1ull);
+}
+__device__ __forceinline__ void bb_clear(BB &b, int s)
+{
+    if (s < 64) b.lo &= ~(1ull << s); else b.hi &= ~(1ull << (s - 64));
+}
+__device__ __forceinline__ void bb_set(BB &b, int s)
+{
+    if (s < 64) b.lo |= (1ull << s); else b.hi |= (1ull << (s - 64));
+}
+// `width` bits starting at bit `sh` (width <= 10, sh + width <= 90)
+__device__ __forceinline__ uint32_t bb_field(const BB &b, int sh, int width)
+{
+    uint64_t v;
+    if (sh < 64) {
+        v = b.lo >> sh;
+        if (sh + width > 64) v |= b.hi << (64 - sh);
+    } else {
+        v = b.hi >> (sh - 64);
+    }
+    return (uint32_t)v & ((1u << width) - 1u);
+}
+// row-major board: row r = 9 bits at 9r.  column-major board: column c = 10 bits at 10c.
+__device__ __forceinline__ uint32_t row_bits(const BB &rm, int r) { return bb_field(rm, 9 * r, 9); }
+__device__ __forceinline__ uint32_t col_bits(const BB &cm, int c) { return bb_field(cm, 10 * c, 10); }
+__device__ __forceinline__ int cm_index(int s) { return (s % 9) * 10 + s / 9; }
+
+// Wave-uniform view of a board held in LDS (all fields identical in every lane).
+struct BoardView {
+    BB occ, occC;        // occupancy row-major / column-major
+    BB red, blk;         // piece sets by colour (row-major)
+    int pA, pB;          // per lane: piece on square lane, and on square 64+lane (lane < 26)
+};
+
+__device__ __forceinline__ BoardView load_view(const int8_t *bd)
+{
+    BoardView v;
+    const int lane = XQ_LANE;
+    v.pA = bd[lane];
+    v.pB = (lane < 26) ? bd[64 + lane] : 0;
+    v.occ.lo = __ballot(v.pA != 0);  v.occ.hi = __ballot(v.pB != 0);
+    v.red.lo = __ballot(v.pA > 0);   v.red.hi = __ballot(v.pB > 0);
+    v.blk.lo = __ballot(v.pA < 0);   v.blk.hi = __ballot(v.pB < 0);
+    int qA = bd[(lane % 10) * 9 + lane / 10];
+    int s2 = 64 + lane;
+    int qB = (lane < 26) ? bd[(s2 % 10) * 9 + s2 / 10] : 0;
+    v.occC.lo = __ballot(qA != 0);   v.occC.hi = __ballot(qB != 0);
+    return v;
+}
+
+// piece on square s (s wave-uniform) out of the per-lane registers of a view
+__device__ __forceinline__ int view_piece(const BoardView &v, int s)
+{
+    s = uni(s);
+    return (s < 64) ? __builtin_amdgcn_readlane(v.pA, s) : __builtin_amdgcn_readlane(v.pB, s - 64);
+}
+
+__device__ __forceinline__ bool in_palace(int X, int r, int c)
+{
+    return (X == 1 ? (r >= 7 && r <= 9) : (r >= 0 && r <= 2)) && c >= 3 && c <= 5;
+}
+
+// Does the piece of type `et` on square `es` (both wave-uniform), moving by the generator rules
+// of side X (chess_env.py:127,143,159,240 key on current_player — Appendix A1), have the
+// square k (per lane) among its pseudo-moves on the occupancy (rm, cm) (per lane)?
+__device__ __forceinline__ bool attacks(int et, int es, int k, const BB &rm, const BB &cm, int X)
+{
+    const int er = es / 9, ec = es % 9, kr = k / 9, kc = k % 9;
+    const int dr = kr - er, dc = kc - ec;
+    const int adr = dr < 0 ? -dr : dr, adc = dc < 0 ? -dc : dc;
+    switch (et) {
+    case ROOK:
+    case CANNON: {
+        if (es == k) return false;
+        int n;
+        if (dr == 0) {
+            int lo = ec < kc ? ec : kc, hi = ec < kc ? kc : ec;
+            n = __builtin_popcount(row_bits(rm, kr) & (((1u << (hi - lo - 1)) - 1u) << (lo + 1)));
+        } else if (dc == 0) {
+            int lo = er < kr ? er : kr, hi = er < kr ? kr : er;
+            n = __builtin_popcount(col_bits(cm, kc) & (((1u << (hi - lo - 1)) - 1u) << (lo + 1)));
+        } else return false;
+        if (et == ROOK) return n == 0;
+        // cannon (chess_env.py:215-235): an empty k is reached only before the screen; an
+        // occupied k only as the first piece behind the screen
+        return bb_test(rm, k) ? (n == 1) : (n == 0);
+    }
+    case KNIGHT: {
+        int leg;
+        if (adr == 2 && adc == 1) leg = (er + dr / 2) * 9 + ec;
+        else if (adr == 1 && adc == 2) leg = er * 9 + ec + dc / 2;
+        else return false;
+        return !bb_test(rm, leg);
+    }
+    case PAWN: {
+        int fwd = (X == 1) ? -1 : 1;
+        bool crossed = (X == 1) ? (er < 5) : (er >= 5);
+        return (dr == fwd && dc == 0) || (crossed && dr == 0 && adc == 1);
+    }
+    case KING:
+        return (adr + adc == 1) && in_palace(X, kr, kc);
+    case ADVISOR:
+        return (adr == 1 && adc == 1) && in_palace(X, kr, kc);
+    case BISHOP: {
+        if (!(adr == 2 && adc == 2)) return false;
+        if (X == 1 ? (kr < 5) : (kr >= 4)) return false;        // chess_env.py:159-170 (river 5 / 4)
+        return !bb_test(rm, (er + dr / 2) * 9 + ec + dc / 2);
+    }
+    default:
+        return false;
+    }
+}
+
+// chess_env.py:506-548 restated as an attack test: is square k attacked by any piece of the
+// set `att` (wave-uniform bitboard over the ORIGINAL board `v`), on the per-lane occupancy
+// (rm, cm), skipping the piece on `skip` (captured by the candidate move), under rules X?
+__device__ __forceinline__ bool attacked_by(const BoardView &v, const BB &att, int k, int skip,
+                                            const BB &rm, const BB &cm, int X)
+{
+    bool hit = false;
+    for (uint64_t m = att.lo; m; m &= m - 1) {
+        int es = uni(__builtin_ctzll(m));
+        int et = __builtin_amdgcn_readlane(v.pA, es);
+        et = et < 0 ? -et : et;
+        hit |= (es != skip) && attacks(et, es, k, rm, cm, X);
+    }
+    for (uint64_t m = att.hi; m; m &= m - 1) {
+        int b = uni(__builtin_ctzll(m));
+        int et = __builtin_amdgcn_readlane(v.pB, b);
+        et = et < 0 ? -et : et;
+        hit |= (64 + b != skip) && attacks(et, 64 + b, k, rm, cm, X);
+    }
+    return hit;
+}
+
+// chess_env.py:466-495 on cached king squares
+__device__ __forceinline__ bool kings_facing(int rk, int bk, const BB &cm)
+{
+    if (rk < 0 || bk < 0) return false;
+    int rc = rk % 9, bc = bk % 9;
+    if (rc != bc) return false;
+    int rr = rk / 9, br = bk / 9;
+    int lo = rr < br ? rr : br, hi = rr < br ? br : rr;
+    if (hi - lo < 1) return true;          // same square: empty range -> "facing" (as the reference)
+    return (col_bits(cm, rc) & (((1u << (hi - lo - 1)) - 1u) << (lo + 1))) == 0;
+}
+
+// _is_in_check(player) evaluated with self.current_player == X (wave-uniform result)
+__device__ __forceinline__ bool in_check(const BoardView &v, int player, int X, int rk, int bk)
+{
+    int k = (player == 1) ? rk : bk;
+    if (k < 0) return false;
+    const BB &att = (player == 1) ? v.blk : v.red;
+    return attacked_by(v, att, k, -1, v.occ, v.occC, X);
+}
+
+// ---------------------------------------------------------------- wave scan helper
+__device__ __forceinline__ int wave_incl_scan(int x)
+{
+    const int lane = XQ_LANE;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int y = __shfl_up(x, d, 64);
+        if (lane >= d) x += y;
+    }
+    return x;
+}
+
+// ---------------------------------------------------------------- legal move generation
+// chess_env.py:76-121.  Output order is part of the contract: own pieces in row-major square
+// order, per piece the generator's emission order, filters keep order.
+// Lane mapping for candidates: lane = (own piece index & 15) * 4 + direction slot.
+// cand / out: LDS u16[128]; own_sq: LDS u8[32].  Returns the (wave-uniform) number of legal moves.
+__device__ int wave_movegen(const int8_t *bd, const BoardView &v, int side, int rk, int bk,
+                            uint16_t *cand, uint16_t *out, uint8_t *own_sq)
+{
+    const int lane = XQ_LANE;
+    const BB &own = (side == 1) ? v.red : v.blk;
+    const BB &ene = (side == 1) ? v.blk : v.red;
+    const int n_lo = __builtin_popcountll(own.lo);
+    const int n_own = n_lo + __builtin_popcountll(own.hi);
+
+    // own piece list in row-major order
+    if (bb_test(own, lane) && lane < 64) {
+        int rank = __builtin_popcountll(own.lo & ((1ull << lane) - 1ull));
+        if (rank < 32) own_sq[rank] = (uint8_t)lane;
+    }
+    if (lane < 26 && ((own.hi >> lane) & 1ull)) {
+        int rank = n_lo + __builtin_popcountll(own.hi & ((1ull << lane) - 1ull));
+        if (rank < 32) own_sq[rank] = (uint8_t)(64 + lane);
+    }
+    wave_sync();
+
+    int n_cand = 0;
+    const int d = lane & 3;
+    for (int chunk = 0; chunk < n_own && chunk < 32; chunk += 16) {
+        const int pi = chunk + (lane >> 2);
+        int cnt = 0, n1 = 0, x0 = -1, x1 = -1, delta = 0, sq = 0;
+        if (pi < n_own && pi < 32) {
+            sq = own_sq[pi];
+            const int r = sq / 9, c = sq % 9;
+            int tp = bd[sq];
+            tp = tp < 0 ? -tp : tp;
+            if (tp == ROOK || tp == CANNON) {
+                // ray order right, left, down, up (chess_env.py:203,218)
+                const bool horiz = d < 2, fwd = (d & 1) == 0;
+                const uint32_t line = horiz ? row_bits(v.occ, r) : col_bits(v.occC, c);
+                const int p = horiz ? c : r, len = horiz ? 9 : 10;
+                delta = horiz ? (fwd ? 1 : -1) : (fwd ? 9 : -9);
+                int n_empty, blk = -1, cap = -1;
+                if (fwd) {
+                    uint32_t x = line >> (p + 1);
+                    if (x == 0) n_empty = len - 1 - p;
+                    else {
+                        int t = __builtin_ctz(x);
+                        n_empty = t; blk = p + 1 + t;
+                        uint32_t y = x >> (t + 1);
+                        if (y) cap = blk + 1 + __builtin_ctz(y);
+                    }
+                } else {
+                    uint32_t x = line & ((1u << p) - 1u);
+                    if (x == 0) n_empty = p;
+                    else {
+                        int hb = 31 - __builtin_clz(x);
+                        n_empty = p - 1 - hb; blk = hb;
+                        uint32_t y = x & ((1u << hb) - 1u);
+                        if (y) cap = 31 - __builtin_clz(y);
+                    }
+                }
+                n1 = n_empty;
+                if (tp == ROOK) {
+                    if (blk >= 0) {
+                        int bs = horiz ? r * 9 + blk : blk * 9 + c;
+                        if (!bb_test(own, bs)) n1 += 1;      // contiguous with the empties
+                    }
+                } else if (cap >= 0) {
+                    int cs = horiz ? r * 9 + cap : cap * 9 + c;
+                    if (!bb_test(own, cs)) x0 = cs;
+                }
+            } else {
+                int ar = -1, ac = -1, br2 = -1, bc2 = -1;       // up to two explicit targets
+                bool okA = false, okB = false;
+                if (tp == KNIGHT) {
+                    // offsets (2,1),(2,-1) | (-2,1),(-2,-1) | (1,2),(-1,2) | (1,-2),(-1,-2); each
+                    // pair shares its leg (chess_env.py:182-187)
+                    int lr, lc;
+                    if (d < 2) { int s = d == 0 ? 1 : -1; lr = r + s; lc = c; ar = r + 2 * s; ac = c + 1; br2 = ar; bc2 = c - 1; }
+                    else { int s = d == 2 ? 1 : -1; lr = r; lc = c + s; ac = c + 2 * s; ar = r + 1; bc2 = ac; br2 = r - 1; }
+                    bool leg_ok = lr >= 0 && lr < 10 && lc >= 0 && lc < 9 && !bb_test(v.occ, lr * 9 + lc);
+                    okA = okB = leg_ok;
+                } else if (tp == KING) {
+                    ar = r + (d == 2 ? 1 : d == 3 ? -1 : 0);
+                    ac = c + (d == 0 ? 1 : d == 1 ? -1 : 0);
+                    okA = in_palace(side, ar, ac);
+                } else if (tp == ADVISOR) {
+                    ar = r + (d < 2 ? 1 : -1);
+                    ac = c + ((d & 1) == 0 ? 1 : -1);
+                    okA = in_palace(side, ar, ac);
+                } else if (tp == BISHOP) {
+                    int sr = d < 2 ? 1 : -1, sc = (d & 1) == 0 ? 1 : -1;
+                    ar = r + 2 * sr; ac = c + 2 * sc;
+                    okA = ar >= 0 && ar < 10 && ac >= 0 && ac < 9 &&
+                          !(side == 1 ? (ar < 5) : (ar >= 4)) && !bb_test(v.occ, (r + sr) * 9 + c + sc);
+                } else if (tp == PAWN) {
+                    int fw = side == 1 ? -1 : 1;
+                    bool crossed = side == 1 ? (r < 5) : (r >= 5);
+                    if (d == 0) { ar = r + fw; ac = c; okA = true; }
+                    else if (d == 1) { ar = r; ac = c - 1; okA = crossed; }
+                    else if (d == 2) { ar = r; ac = c + 1; okA = crossed; }
+                }
+                okA = okA && ar >= 0 && ar < 10 && ac >= 0 && ac < 9 && !bb_test(own, ar * 9 + ac);
+                okB = okB && br2 >= 0 && br2 < 10 && bc2 >= 0 && bc2 < 9 && !bb_test(own, br2 * 9 + bc2);
+                int ta = okA ? ar * 9 + ac : -1, tb = okB ? br2 * 9 + bc2 : -1;
+                x0 = okA ? ta : tb;
+                x1 = okA ? tb : -1;
+            }
+            cnt = n1 + (x0 >= 0) + (x1 >= 0);
+        }
+        const int incl = wave_incl_scan(cnt);
+        const int base = n_cand + incl - cnt;
+        for (int k = 0; k < 10; k++) {
+            if (k < cnt) {
+                int t = (k < n1) ? sq + (k + 1) * delta : (k == n1 ? x0 : x1);
+                if (base + k < MAXM) cand[base + k] = (uint16_t)(sq * 90 + t);
+            }
+        }
+        n_cand += __shfl(incl, 63, 64);
+    }
+    if (n_cand > MAXM) n_cand = MAXM;
+    wave_sync();
+
+    // suicide filter (chess_env.py:431-464): apply on a private occupancy, test the own king
+    int n_out = 0;
+    for (int base = 0; base < n_cand; base += 64) {
+        const int j = base + lane;
+        bool legal = false;
+        int mv = 0;
+        if (j < n_cand) {
+            mv = cand[j];
+            const int f = mv / 90, t = mv % 90;
+            const int P = bd[f];
+            BB rm = v.occ, cm = v.occC;
+            bb_clear(rm, f); bb_set(rm, t);
+            bb_clear(cm, cm_index(f)); bb_set(cm, cm_index(t));
+            const int rk2 = (P == KING) ? t : rk, bk2 = (P == -KING) ? t : bk;   // only a moving king (A5)
+            const int k = (side == 1) ? rk2 : bk2;
+            bool bad = false;
+            if (k >= 0) bad = attacked_by(v, ene, k, t, rm, cm, side);
+            legal = !(bad || kings_facing(rk2, bk2, cm));
+        } else {
+            // keep the uniform loops of attacked_by convergent: nothing to do for idle lanes
+        }
+        const uint64_t mask = __ballot(legal);
+        if (legal) out[n_out + __builtin_popcountll(mask & ((1ull << lane) - 1ull))] = (uint16_t)mv;
+        n_out += __builtin_popcountll(mask);
+    }
+    wave_sync();
+    return n_out;
+}
+
+// ---------------------------------------------------------------- board packing (HBM form)
+// 4 bits per square: 0 empty, 1..7 red K,A,B,N,R,C,P, 8..14 black; 12 dwords = 48 B per board.
+__device__ __forceinline__ uint32_t pack_dword(const int8_t *bd, int i)      // squares 8i..8i+7
+{
+    uint32_t w = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        int s = 8 * i + j;
+        int p = (s < 90) ? bd[s] : 0;
+        uint32_t code = p > 0 ? (uint32_t)p : (p < 0 ? (uint32_t)(7 - p) : 0u);
+        w |= code << (4 * j);
+    }
+    return w;
+}
+
+__device__ __forceinline__ void unpack_to_lds(const uint32_t *packed, int8_t *bd)
+{
+    const int lane = XQ_LANE;
+    if (lane < 12) {
+        uint32_t w = packed[lane];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            uint32_t code = (w >> (4 * j)) & 15u;
+            int p = code <= 7 ? (int)code : 7 - (int)code;
+            bd[8 * lane + j] = (int8_t)p;
+        }
+    }
+}
+
+__device__ __forceinline__ uint64_t mix64(uint64_t x)
+{
+    x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ull;
+    x ^= x >> 27; x *= 0x94d049bb133111ebull;
+    x ^= x >> 31;
+    return x;
+}
+
+// Position key for the repetition rule (chess_env.py:497-504): the reference compares 64-bit
+// Python hashes of board bytes + mover byte; only equality matters, so any 64-bit key of the
+// same information is an equivalent contract.  Zobrist-style XOR over the 12 packed dwords.
+__device__ __forceinline__ uint64_t position_key(const int8_t *bd, int player_byte)
+{
+    const int lane = XQ_LANE;
+    uint64_t h = 0;
+    if (lane < 12) h = mix64(((uint64_t)(lane + 1) << 32) | pack_dword(bd, lane));
+#pragma unroll
+    for (int d = 1; d < 16; d <<= 1) {
+        uint32_t lo = __shfl_xor((uint32_t)h, d, 64), hi = __shfl_xor((uint32_t)(h >> 32), d, 64);
+        h ^= ((uint64_t)hi << 32) | lo;
+    }
+    uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)h), hi = __builtin_amdgcn_readfirstlane((uint32_t)(h >> 32));
+    h = ((uint64_t)hi << 32) | lo;
+    return mix64(h ^ (0x9E3779B97F4A7C15ull * (uint64_t)(player_byte + 1)));
+}
+
+// ---------------------------------------------------------------- make_move
+struct MState {          // wave-uniform scalar state of one env (chess_env.py:14-67 attributes)
+    int side, move_count, winner, reason, reason_side, reason_count;
+    int rk, bk, nocap, cchk;
+};
+
+// chess_env.py:683-737 (uses the board AFTER the move and the mover as current_player)
+__device__ __forceinline__ double position_change(int type, int side, int from, int to, int rk, int bk)
+{
+    const int fr = from / 9, fc = from % 9, tr = to / 9, tc = to % 9;
+    double score = 0;
+    const int advance = side == 1 ? fr - tr : tr - fr;
+    if (advance > 0) {
+        if (type == PAWN) score += advance * 2.0;
+        else if (type == ROOK || type == CANNON) score += advance * 1.5;
+        else if (type == KNIGHT) score += advance * 1.0;
+    }
+    if (tc >= 3 && tc <= 5) {
+        score += 1.5;
+        if (tr >= 3 && tr <= 6) score += 1.0;
+    }
+    if (type == PAWN) {
+        if (side == 1 && tr < 5) score += 3.0;
+        else if (side == -1 && tr >= 5) score += 3.0;
+    }
+    const int ok = side == 1 ? bk : rk;
+    if (ok >= 0) {
+        const int kr = ok / 9, kc = ok % 9;
+        const int od = abs(fr - kr) + abs(fc - kc), nd = abs(tr - kr) + abs(tc - kc);
+        if (nd < od) score += (od - nd) * 0.5;
+    }
+    return score;
+}
+
+struct MoveResult {
+    double reward;
+    int done, is_check, n_legal;
+    uint64_t key;          // position_history entry appended by this move
+};
+
+// History access is abstracted so that the same cascade serves the real game (HBM history), the
+// in-search envs (path-local history, starts empty: self_play.py:173-174) and the C-ABI rules
+// entry points (host-provided history).
+//   hist.count_key(key)      -> occurrences of key among the entries recorded so far (incl. new one)
+//   hist.perpetual(is_check) -> >= 10 checks among the last 12 entries incl. the new one, len >= 12
+//
+// The board in LDS is updated in place; `legal` receives the legal moves of the NEW side to move
+// when the game is not over by king capture (they double as the next position's move list).
+template <bool WANT_REWARD, bool WANT_CHECK, class Hist>
+__device__ MoveResult wave_make_move(int8_t *bd, MState &s, int move, Hist &hist,
+                                     uint16_t *cand, uint16_t *legal, uint8_t *own_sq)
+{
+    const int lane = XQ_LANE;
+    const int from = move / 90, to = move % 90;
+    const int captured = bd[to], moving = bd[from];
+    wave_sync();
+    if (lane == 0) { bd[to] = (int8_t)moving; bd[from] = 0; }
+    wave_sync();
+
+    if (moving == KING) s.rk = to; else if (moving == -KING) s.bk = to;           // :271-274
+    if (captured == KING) s.rk = NO_KING; else if (captured == -KING) s.bk = NO_KING;   // :276-279
+    if (captured != 0) s.nocap = 0; else s.nocap += 1;                             // :282-285
+
+    MoveResult res;
+    res.reward = 0; res.done = 0; res.n_legal = 0;
+    const int acap = captured < 0 ? -captured : captured;
+    if (acap == KING) {                                                            // :292-297
+        s.winner = s.side; res.reward = 100; res.done = 1;
+        s.reason = R_KING_CAPTURED; s.reason_side = s.side;
+    } else if (WANT_REWARD && captured != 0) {                                     // :300-314
+        double base = acap == ROOK ? 9 : acap == CANNON ? 4.5 : acap == KNIGHT ? 4 :
+                      acap == BISHOP ? 2 : acap == ADVISOR ? 2 : acap == PAWN ? 1 : 0;
+        res.reward = base * 2.0;
+        if (acap == ADVISOR || acap == BISHOP) res.reward += 3.0;
+    }
+
+    BoardView v = load_view(bd);
+    int is_checking = 0;
+    if (WANT_CHECK) is_checking = in_check(v, -s.side, s.side, s.rk, s.bk) ? 1 : 0;   // :317
+    res.is_check = is_checking;
+    if (!res.done && is_checking) {                                                // :318-327
+        if (WANT_REWARD) {
+            if (s.cchk == 0) res.reward += 15.0;
+            else if (s.cchk == 1) res.reward += 10.0;
+            else if (s.cchk == 2) res.reward += 5.0;
+        }
+        s.cchk += 1;
+    } else {                                                                       // :328-335
+        s.cchk = 0;
+        if (WANT_REWARD && captured == 0 && !res.done) {
+            int tp = moving < 0 ? -moving : moving;
+            double pr = position_change(tp, s.side, from, to, s.rk, s.bk);
+            res.reward += pr * 0.01;
+        }
+    }
+
+    res.key = hist.want_keys() ? position_key(bd, s.side == 1 ? 0 : 1) : 0ull;    // :338 (mover byte)
+    hist.push(res.key, is_checking);                                               // :338-345
+
+    s.side = -s.side;                                                              // :348-349
+    s.move_count += 1;
+
+    if (!res.done) {                                                               // :352-397
+        const int nl = wave_movegen(bd, v, s.side, s.rk, s.bk, cand, legal, own_sq);
+        res.n_legal = nl;
+        const bool in_chk = (nl == 0) ? in_check(v, s.side, s.side, s.rk, s.bk) : false;
+        if (nl == 0 && in_chk) {                                                   // :354-359
+            res.done = 1; res.reward = 200; s.winner = -s.side;
+            s.reason = R_CHECKMATE; s.reason_side = s.side;
+        } else if (hist.want_keys() && hist.count_key(position_key(bd, s.side == 1 ? 0 : 1)) >= 3) {   // :362-366, 598-605
+            res.done = 1; res.reward = 0; s.winner = 0; s.reason = R_REPETITION; s.reason_side = 0;
+        } else if (s.nocap >= 100) {                                               // :369-373, 612
+            res.done = 1; res.reward = 0; s.winner = 0; s.reason = R_FIFTY; s.reason_side = 0;
+        } else if (nl == 0) {                                                      // :376-381
+            res.done = 1; res.reward = 100; s.winner = -s.side;
+            s.reason = R_STALEMATE; s.reason_side = s.side;
+        } else if (hist.perpetual()) {                                             // :384-389, 646-662
+            res.done = 1; res.reward = -10; s.winner = -s.side;
+            s.reason = R_PERP_CHECK; s.reason_side = s.side;
+        }
+    }
+    if (!res.done && s.move_count >= 70) {                                         // :400-404
+        res.done = 1; res.reward = -2; s.winner = 0;
+        s.reason = R_MOVE_CAP; s.reason_side = 0; s.reason_count = s.move_count;
+    }
+    return res;
+}
+
+}  // namespace xq

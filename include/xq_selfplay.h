@@ -1,0 +1,214 @@
+/*
+ * xq_selfplay.h — C ABI of the MI355X-native batched self-play engine (libxq_hip.so).
+ *
+ * The reference (hpy666666/ChineseChessAI) is pure Python and has no FFI layer; its boundary
+ * for this hot path is the Python call surface of chess_env.py / self_play.py
+ * (SURVEY.md §8b).  The entry points below are what a ctypes binding of THAT surface needs;
+ * each cites the reference interface it replaces.  The reference-side stub a maintainer would
+ * add is shown in INTEGRATION.md; the in-tree host mirror is chinesechessai_amd/*.py.
+ *
+ * Conventions: extern "C", plain pointers and sizes, no exceptions across the boundary, return
+ * 0 on success or a negative XQ_E_* code; xq_last_error() gives the message.  Handles are
+ * thread-compatible (one thread at a time per handle).  Pointers named *_host are host memory,
+ * *_dev are device (HBM) memory on the engine's device.  All launches go to the stream given to
+ * xq_engine_set_stream (a hipStream_t; NULL = default stream), so they order with the caller's
+ * own work on that stream (e.g. the PyTorch-ROCm network forward).
+ *
+ * Encodings shared by every call:
+ *   board   int8[90], row-major 10x9, codes +1..+7 red K,A,B,N,R,C,P / -1..-7 black
+ *           (config.py:66-74; row 0 = black back rank — chess_env.py:33-60)
+ *   move    uint16 = (from_row*9+from_col)*90 + to_row*9+to_col — the same index the reference
+ *           uses into its 8100 policy logits (neural_network.py:160)
+ *   king    cached square row*9+col or -1 for None (chess_env.py:27-28)
+ *   winner  1, -1, 0, or XQ_WINNER_NONE (Python None)
+ */
+#ifndef XQ_SELFPLAY_H
+#define XQ_SELFPLAY_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define XQ_MAX_MOVES    128
+#define XQ_MAX_PLIES    70      /* literal 70 of chess_env.py:400 */
+#define XQ_WINNER_NONE  2
+#define XQ_NO_KING      (-1)
+#define XQ_POLICY_SIZE  8100
+
+#define XQ_E_INVALID    (-1)    /* bad argument                                   */
+#define XQ_E_HIP        (-2)    /* HIP runtime error                              */
+#define XQ_E_NOGPU      (-3)    /* no usable gfx950 device                        */
+#define XQ_E_STATE      (-4)    /* call out of sequence                           */
+
+/* end_reason codes (chess_env.py:297,359,366,373,381,389,397,404); the host formats the strings */
+enum {
+    XQ_R_NONE = 0, XQ_R_KING_CAPTURED = 1, XQ_R_CHECKMATE = 2, XQ_R_REPETITION = 3, XQ_R_FIFTY = 4,
+    XQ_R_STALEMATE = 5, XQ_R_PERP_CHECK = 6, XQ_R_PERP_CHASE = 7, XQ_R_MOVE_CAP = 8
+};
+
+/* evaluator-output kinds accepted by the tree kernels */
+enum {
+    XQ_EVAL_PRIORS = 0,       /* a = float32 priors[G][128] in legal-move order, v = float64 values[G]   */
+    XQ_EVAL_LOGITS_F32 = 1,   /* a = float32 logits[G][8100], v = float32 values[G]                      */
+    XQ_EVAL_LOGITS_BF16 = 2   /* a = bf16 logits[G][8100],    v = bf16 values[G]                         */
+};
+
+/* layouts of the network-input planes the search kernel writes (neural_network.py:128-146) */
+enum {
+    XQ_PLANES_NONE = 0,
+    XQ_PLANES_NCHW_F32 = 1,   /* float32 [G][15][10][9]  — exactly encode_board()                       */
+    XQ_PLANES_NCHW_BF16 = 2,  /* bf16    [G][15][10][9]                                                  */
+    XQ_PLANES_NHWC16_BF16 = 3 /* bf16    [G][10][9][16]  — channels-last, channel 15 = 0 padding        */
+};
+
+const char *xq_last_error(void);
+int xq_device_count(void);
+/* 1 when the library was built for the visible device's architecture (gfx950) */
+int xq_device_ok(int device);
+
+/* ------------------------------------------------------------------------------------------
+ * Rules entry points on host buffers (batch of n independent envs).  They back the host mirror
+ * of class ChineseChess (chess_env.py:9) one call at a time and the parity tests in bulk.
+ * ------------------------------------------------------------------------------------------ */
+
+/* ChineseChess.get_legal_moves (chess_env.py:76-121).  moves_host[n][128], counts_host[n]. */
+int xq_rules_legal_moves(int n, const int8_t *boards_host, const int32_t *player_host,
+                         const int32_t *red_king_host, const int32_t *black_king_host,
+                         uint16_t *moves_host, int32_t *counts_host);
+
+/* _is_in_check(1), _is_in_check(-1), _are_kings_facing (chess_env.py:506-548, 466-495) as seen
+ * with self.current_player == player_host[i].  Each out array int32[n]. */
+int xq_rules_query(int n, const int8_t *boards_host, const int32_t *player_host,
+                   const int32_t *red_king_host, const int32_t *black_king_host,
+                   int32_t *in_check_red_host, int32_t *in_check_black_host, int32_t *facing_host);
+
+/* ChineseChess.make_move (chess_env.py:253-406).
+ * state_host: int32[n][XQ_STATE_WORDS], updated in place; boards_host updated in place.
+ * Histories: pos_hist_host uint64[n][hist_stride] holds n_hist[i] keys previously returned in
+ * key_out_host (position_history), check_hist_host uint8[n][hist_stride] holds n_check[i] flags
+ * (check_history); the call does NOT append — it returns the new entry for the caller to append.
+ * next_moves_host/next_count_host receive the legal moves of the new side to move (valid when the
+ * game did not end by king capture). */
+#define XQ_STATE_WORDS 10
+enum { XQ_S_PLAYER = 0, XQ_S_MOVE_COUNT = 1, XQ_S_WINNER = 2, XQ_S_RED_KING = 3, XQ_S_BLACK_KING = 4,
+       XQ_S_NO_CAPTURE = 5, XQ_S_CONSEC_CHECKS = 6, XQ_S_REASON = 7, XQ_S_REASON_SIDE = 8,
+       XQ_S_REASON_COUNT = 9 };
+int xq_rules_make_move(int n, int8_t *boards_host, int32_t *state_host, const int32_t *move_host,
+                       const uint64_t *pos_hist_host, const int32_t *n_hist_host,
+                       const uint8_t *check_hist_host, const int32_t *n_check_host, int hist_stride,
+                       double *reward_host, int32_t *done_host, int32_t *is_check_host,
+                       uint64_t *key_out_host, uint16_t *next_moves_host, int32_t *next_count_host);
+
+/* ------------------------------------------------------------------------------------------
+ * Engine: G concurrent games, one wavefront per game, state resident in HBM.
+ * Replaces MCTS.search (self_play.py:89-154), self_play_game (self_play.py:178-312) and the
+ * process pool of parallel_self_play (self_play.py:368-469).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct xq_engine xq_engine;
+
+typedef struct {
+    int32_t n_games;          /* G                                                             */
+    int32_t sims;             /* MCTS simulations per move (config.py:10)                      */
+    int32_t leaf_batch;       /* 8 (self_play.py:101)                                          */
+    int32_t max_moves;        /* config.MAX_MOVES = 70 (config.py:9)                           */
+    double  temperature;      /* self_play_game(temperature=...)                               */
+    int32_t opponent_mode;    /* 1: only red plies are stored (self_play.py:234)               */
+    int32_t planes_format;    /* XQ_PLANES_*                                                   */
+    int32_t device;           /* HIP device ordinal                                            */
+    int32_t reserved;
+} xq_config;
+
+int  xq_engine_create(const xq_config *cfg, xq_engine **out);
+void xq_engine_destroy(xq_engine *e);
+int  xq_engine_set_stream(xq_engine *e, void *hip_stream);
+
+/* counts ** (1/temperature) as the HOST's numpy evaluates it, for counts 0..n-1 (self_play.py:230);
+ * NULL/0 = identity (temperature 1.0). */
+int  xq_engine_set_pow_table(xq_engine *e, const double *table_host, int n);
+
+/* Start G fresh games (ChineseChess.reset, chess_env.py:14-67).  seeds_host[g] seeds game g's
+ * private MT19937 stream exactly as np.random.seed(seed) would (self_play.py:242 draws one
+ * double per ply from it). */
+int  xq_engine_new_games(xq_engine *e, const uint32_t *seeds_host);
+
+/* Replace the root states (MCTS.search on caller-provided envs; _copy_env semantics of
+ * self_play.py:156-175: board, player, move_count, winner, king caches, no_capture_count). */
+int  xq_engine_set_roots(xq_engine *e, const int8_t *boards_host, const int32_t *state_host /*[G][XQ_STATE_WORDS]*/);
+
+/* One leaf-batch round r (0-based) of MCTS.search for every game (self_play.py:103-148):
+ *  - if r > 0, first consumes the evaluator output of round r-1 (expand + backups),
+ *  - runs the round's simulations (select / make_move / terminal backups) on the frozen tree,
+ *  - leaves at most one pending leaf per game: planes, packed board, legal moves, multiplicity.
+ * eval_a_dev / eval_v_dev per eval_kind; ignored for r == 0.  planes_dev may be NULL. */
+int  xq_engine_search_round(xq_engine *e, int round, int eval_kind, const void *eval_a_dev,
+                            const void *eval_v_dev, void *planes_dev);
+
+/* Built-in exact evaluator ("HashNet") on the pending leaves; fills the
+ * engine's own priors/values buffers (use XQ_EVAL_PRIORS with xq_engine_priors_ptr/values_ptr). */
+int  xq_engine_eval_hashnet(xq_engine *e, int salt);
+
+/* Consume the last round's evaluator output; afterwards root visit counts are final
+ * (the return value of MCTS.search, self_play.py:151-154). */
+int  xq_engine_end_search(xq_engine *e, int eval_kind, const void *eval_a_dev, const void *eval_v_dev);
+
+/* One ply of self_play_game after the search (self_play.py:219-256): visit counts -> pi,
+ * sample record, np.random.choice, make_move, next root.  Call after xq_engine_end_search. */
+int  xq_engine_play_move(xq_engine *e);
+
+/* z assignment (self_play.py:259-310) for all games. */
+int  xq_engine_finalize(xq_engine *e);
+
+/* number of games still running (synchronises the stream) */
+int  xq_engine_active_games(xq_engine *e, int32_t *n_active_host);
+
+/* device pointers of engine-owned buffers (valid for the engine's lifetime) */
+void *xq_engine_priors_ptr(xq_engine *e);      /* float32 [G][128]  */
+void *xq_engine_values_ptr(xq_engine *e);      /* float64 [G]       */
+int   xq_engine_rounds_per_move(xq_engine *e); /* ceil(sims / leaf_batch) */
+
+/* ---- read-back (each synchronises the stream) ---- */
+/* pending leaves after xq_engine_search_round: rows for predict_batch (self_play.py:139-143) */
+int  xq_engine_read_leaves(xq_engine *e, int8_t *boards_host /*[G][90]*/, int32_t *player_host,
+                           uint16_t *moves_host /*[G][128]*/, int32_t *n_moves_host,
+                           int32_t *mult_host /* 0 = no pending leaf */);
+int  xq_engine_write_priors(xq_engine *e, const float *priors_host /*[G][128]*/, const double *values_host);
+/* root children after xq_engine_end_search */
+int  xq_engine_read_root_visits(xq_engine *e, uint16_t *moves_host /*[G][128]*/, int32_t *visits_host,
+                                int32_t *n_child_host);
+/* per-game outcome: winner (0 for None, self_play.py:259), reason code/side/count, plies, samples, error
+ * (error 1 = np.random.choice would raise ValueError: NaN probabilities, sims <= leaf_batch) */
+int  xq_engine_read_games(xq_engine *e, int32_t *winner_host, int32_t *reason_host, int32_t *reason_side_host,
+                          int32_t *reason_count_host, int32_t *n_plies_host, int32_t *n_samples_host,
+                          int32_t *error_host);
+/* per-sample records, [G][70] leading dims; counts = root visit counts in moves order
+ * (pi = counts**(1/T) / sum is formed by the host mirror with numpy, as the reference does) */
+int  xq_engine_read_samples(xq_engine *e, int8_t *boards_host /*[G][70][90]*/, int8_t *player_host /*[G][70]*/,
+                            uint8_t *n_moves_host /*[G][70]*/, uint16_t *moves_host /*[G][70][128]*/,
+                            uint16_t *counts_host /*[G][70][128]*/, double *z_host /*[G][70]*/,
+                            uint16_t *chosen_host /*[G][70]*/, double *step_reward_host /*[G][70]*/);
+/* device-resident fixed-size sample records for the RCCL all-gather (one per [game][ply]),
+ * record layout: xq_sample_record below.  Returns the device pointer and byte size. */
+typedef struct {
+    uint32_t board[12];       /* nibble-packed board (4 bit / square)                     */
+    double   z;
+    int8_t   player;
+    uint8_t  n_moves;
+    uint8_t  valid;
+    uint8_t  pad;
+    uint16_t chosen;
+    uint16_t pad2;
+    uint16_t moves[XQ_MAX_MOVES];
+    uint16_t counts[XQ_MAX_MOVES];
+} xq_sample_record;
+int  xq_engine_pack_samples(xq_engine *e, void *records_dev /* xq_sample_record[G][70] */);
+
+/* ---- measurement: HIP events recorded on the engine's stream around every tree-kernel launch ---- */
+int  xq_engine_profile(xq_engine *e, int enable);
+int  xq_engine_profile_read(xq_engine *e, double *search_ms_total, int64_t *search_launches,
+                            double *play_ms_total, int64_t *play_launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,211 @@
+"""ctypes binding of the CPU oracle (oracle/xq_oracle.c).
+
+TEST INFRASTRUCTURE ONLY.  Importable from tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg — never from the product package (chinesechessai_amd/).  Parity: PINNED
+(see xq_oracle.h).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libxq_oracle.so")
+
+MAX_MOVES = 128
+HIST_CAP = 2048
+WINNER_NONE = 2
+NO_KING = -1
+
+R_NONE, R_KING_CAPTURED, R_CHECKMATE, R_REPETITION, R_FIFTY, R_STALEMATE, R_PERP_CHECK, \
+    R_PERP_CHASE, R_MOVE_CAP = range(9)
+
+
+class Env(C.Structure):
+    _fields_ = [
+        ("board", C.c_int8 * 90),
+        ("current_player", C.c_int32),
+        ("move_count", C.c_int32),
+        ("winner", C.c_int32),
+        ("end_reason", C.c_int32),
+        ("end_side", C.c_int32),
+        ("end_count", C.c_int32),
+        ("red_king", C.c_int32),
+        ("black_king", C.c_int32),
+        ("no_capture_count", C.c_int32),
+        ("consecutive_checks", C.c_int32),
+        ("n_hist", C.c_int32),
+        ("n_check", C.c_int32),
+        ("pos_hist", (C.c_uint8 * 91) * HIST_CAP),
+        ("check_hist", C.c_uint8 * HIST_CAP),
+    ]
+
+
+EVAL_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int8), C.POINTER(C.c_int32),
+                      C.POINTER(C.c_uint16), C.POINTER(C.c_int32), C.POINTER(C.c_float),
+                      C.POINTER(C.c_double))
+
+
+class Evaluator(C.Structure):
+    _fields_ = [("fn", EVAL_FN), ("ctx", C.c_void_p)]
+
+
+class Game(C.Structure):
+    _fields_ = [
+        ("n_samples", C.c_int32), ("n_plies", C.c_int32), ("winner", C.c_int32),
+        ("end_reason", C.c_int32), ("end_side", C.c_int32), ("end_count", C.c_int32),
+        ("error", C.c_int32),
+        ("s_board", (C.c_int8 * 90) * 70),
+        ("s_player", C.c_int32 * 70),
+        ("s_nmoves", C.c_int32 * 70),
+        ("s_moves", (C.c_uint16 * MAX_MOVES) * 70),
+        ("s_probs", (C.c_double * MAX_MOVES) * 70),
+        ("s_z", C.c_double * 70),
+        ("t_move", C.c_int32 * 70),
+        ("t_nchild", C.c_int32 * 70),
+        ("t_moves", (C.c_uint16 * MAX_MOVES) * 70),
+        ("t_visits", (C.c_int32 * MAX_MOVES) * 70),
+        ("t_reward", C.c_double * 70),
+    ]
+
+
+def build(force=False):
+    """Compile the oracle with gcc (seconds)."""
+    if force or not os.path.exists(_LIB_PATH) or \
+            os.path.getmtime(_LIB_PATH) < os.path.getmtime(os.path.join(_HERE, "xq_oracle.c")):
+        subprocess.check_call(["make", "-C", _HERE, "libxq_oracle.so"], stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB_PATH)
+        L.xqo_env_new.restype = C.POINTER(Env)
+        L.xqo_env_free.argtypes = [C.POINTER(Env)]
+        L.xqo_reset.argtypes = [C.POINTER(Env)]
+        L.xqo_copy_min.argtypes = [C.POINTER(Env), C.POINTER(Env)]
+        L.xqo_legal_moves.argtypes = [C.POINTER(Env), C.POINTER(C.c_uint16)]
+        L.xqo_is_in_check.argtypes = [C.POINTER(Env), C.c_int]
+        L.xqo_are_kings_facing.argtypes = [C.POINTER(Env)]
+        L.xqo_is_move_suicide.argtypes = [C.POINTER(Env), C.c_int, C.c_int]
+        L.xqo_make_move.argtypes = [C.POINTER(Env), C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)]
+        L.xqo_position_change.argtypes = [C.POINTER(Env), C.c_int, C.c_int]
+        L.xqo_position_change.restype = C.c_double
+        L.xqo_mcts_search.argtypes = [C.POINTER(Env), C.c_int, C.POINTER(Evaluator),
+                                      C.POINTER(C.c_uint16), C.POINTER(C.c_int32)]
+        L.xqo_puct_score.argtypes = [C.c_double, C.c_int, C.c_float, C.c_int]
+        L.xqo_puct_score.restype = C.c_float
+        L.xqo_mt_seed.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_int), C.c_uint32]
+        L.xqo_mt_double.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_int)]
+        L.xqo_mt_double.restype = C.c_double
+        L.xqo_np_sum.argtypes = [C.POINTER(C.c_double), C.c_int]
+        L.xqo_np_sum.restype = C.c_double
+        L.xqo_choice_from_uniform.argtypes = [C.POINTER(C.c_double), C.c_int, C.c_double]
+        L.xqo_crc32.argtypes = [C.c_uint32, C.POINTER(C.c_uint8), C.c_int]
+        L.xqo_crc32.restype = C.c_uint32
+        L.xqo_self_play_game.argtypes = [C.POINTER(Evaluator), C.POINTER(Evaluator), C.c_double,
+                                         C.c_int, C.c_int, C.c_uint32, C.POINTER(C.c_double),
+                                         C.POINTER(Game)]
+        L.xqo_z_value.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_double]
+        L.xqo_z_value.restype = C.c_double
+        _lib = L
+    return _lib
+
+
+def hashnet_evaluator():
+    L = lib()
+    fn = C.cast(L.xqo_hashnet_eval, EVAL_FN)
+    return Evaluator(fn, None)
+
+
+def decode_move(m):
+    f, t = divmod(int(m), 90)
+    return (f // 9, f % 9, t // 9, t % 9)
+
+
+def encode_move(mv):
+    fr, fc, tr, tc = mv
+    return (fr * 9 + fc) * 90 + tr * 9 + tc
+
+
+def sq(pos):
+    return NO_KING if pos is None else pos[0] * 9 + pos[1]
+
+
+class OracleEnv:
+    """Thin object wrapper with the reference's ChineseChess surface (used by tests)."""
+
+    def __init__(self):
+        self._L = lib()
+        self.p = self._L.xqo_env_new()
+
+    def __del__(self):
+        try:
+            self._L.xqo_env_free(self.p)
+        except Exception:
+            pass
+
+    @property
+    def e(self):
+        return self.p.contents
+
+    def reset(self):
+        self._L.xqo_reset(self.p)
+
+    def set_state(self, board, player, move_count=0, winner=WINNER_NONE, red_king=NO_KING,
+                  black_king=NO_KING, no_capture=0, consecutive_checks=0):
+        e = self.e
+        b = np.ascontiguousarray(board, dtype=np.int8).reshape(90)
+        C.memmove(e.board, b.ctypes.data, 90)
+        e.current_player = int(player)
+        e.move_count = int(move_count)
+        e.winner = int(winner)
+        e.red_king = int(red_king)
+        e.black_king = int(black_king)
+        e.no_capture_count = int(no_capture)
+        e.consecutive_checks = int(consecutive_checks)
+        e.n_hist = 0
+        e.n_check = 0
+        e.end_reason = 0
+
+    def board(self):
+        return np.frombuffer(self.e.board, dtype=np.int8).reshape(10, 9).copy()
+
+    def legal_moves(self):
+        out = (C.c_uint16 * MAX_MOVES)()
+        n = self._L.xqo_legal_moves(self.p, out)
+        return [int(out[i]) for i in range(n)]
+
+    def make_move(self, move):
+        r = C.c_double()
+        chk = C.c_int()
+        done = self._L.xqo_make_move(self.p, int(move), C.byref(r), C.byref(chk))
+        return r.value, bool(done), bool(chk.value)
+
+    def search(self, sims, evaluator=None):
+        ev = evaluator or hashnet_evaluator()
+        mv = (C.c_uint16 * MAX_MOVES)()
+        vs = (C.c_int32 * MAX_MOVES)()
+        n = self._L.xqo_mcts_search(self.p, sims, C.byref(ev), mv, vs)
+        return [int(mv[i]) for i in range(n)], [int(vs[i]) for i in range(n)]
+
+
+def self_play_game(seed, sims, temperature=1.0, max_moves=70, eval_red=None, eval_black=None,
+                   pow_table=None):
+    L = lib()
+    g = Game()
+    er = eval_red or hashnet_evaluator()
+    pt = None
+    if pow_table is not None:
+        pt = np.ascontiguousarray(pow_table, dtype=np.float64)
+    rc = L.xqo_self_play_game(C.byref(er), C.byref(eval_black) if eval_black else None,
+                              float(temperature), int(sims), int(max_moves), int(seed),
+                              pt.ctypes.data_as(C.POINTER(C.c_double)) if pt is not None else None,
+                              C.byref(g))
+    return rc, g
