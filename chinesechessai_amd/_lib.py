@@ -1,0 +1,127 @@
+"""ctypes binding of libxq_hip.so (include/xq_selfplay.h).
+
+The HIP library is the product: there is NO CPU fallback.  If the shared object is missing or no
+gfx950 device is visible, every compute entry point raises — loudly.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libxq_hip.so")
+SOURCES = [os.path.join(CSRC, "xq_engine.hip")]
+HEADERS = [os.path.join(CSRC, "xq_device.hpp"), os.path.join(_HERE, "..", "include", "xq_selfplay.h")]
+
+MAX_MOVES = 128
+MAX_PLIES = 70
+WINNER_NONE = 2
+NO_KING = -1
+POLICY_SIZE = 8100
+STATE_WORDS = 10
+(S_PLAYER, S_MOVE_COUNT, S_WINNER, S_RED_KING, S_BLACK_KING, S_NO_CAPTURE, S_CONSEC_CHECKS, S_REASON,
+ S_REASON_SIDE, S_REASON_COUNT) = range(10)
+EVAL_PRIORS, EVAL_LOGITS_F32, EVAL_LOGITS_BF16 = 0, 1, 2
+PLANES_NONE, PLANES_NCHW_F32, PLANES_NCHW_BF16, PLANES_NHWC16_BF16 = 0, 1, 2, 3
+SAMPLE_RECORD_BYTES = 48 + 8 + 4 + 4 + 256 + 256
+
+
+class XqError(RuntimeError):
+    pass
+
+
+class Config(C.Structure):
+    _fields_ = [("n_games", C.c_int32), ("sims", C.c_int32), ("leaf_batch", C.c_int32),
+                ("max_moves", C.c_int32), ("temperature", C.c_double), ("opponent_mode", C.c_int32),
+                ("planes_format", C.c_int32), ("device", C.c_int32), ("reserved", C.c_int32)]
+
+
+def hipcc_path():
+    for p in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if p and (os.path.isabs(p) and os.path.exists(p) or not os.path.isabs(p)):
+            return p
+    return "hipcc"
+
+
+def build(force=False, verbose=False):
+    """Cross-compile the HIP library for gfx950 in-tree (works without a GPU)."""
+    deps = SOURCES + HEADERS
+    if not force and os.path.exists(LIB_PATH) and all(
+            os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+        return LIB_PATH
+    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared",
+           "-std=c++17", "-Wall", "-Wno-unused-function", "-o", LIB_PATH] + SOURCES
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+_lib = None
+
+_I8P, _I32P, _U8P, _U16P, _U32P, _U64P, _F32P, _F64P = (C.POINTER(t) for t in (
+    C.c_int8, C.c_int32, C.c_uint8, C.c_uint16, C.c_uint32, C.c_uint64, C.c_float, C.c_double))
+
+_SIGNATURES = {
+    "xq_last_error": (C.c_char_p, []),
+    "xq_device_count": (C.c_int, []),
+    "xq_device_ok": (C.c_int, [C.c_int]),
+    "xq_rules_legal_moves": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "xq_rules_query": (C.c_int, [C.c_int] + [C.c_void_p] * 7),
+    "xq_rules_make_move": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_void_p, C.c_void_p]),
+    "xq_engine_create": (C.c_int, [C.POINTER(Config), C.POINTER(C.c_void_p)]),
+    "xq_engine_destroy": (None, [C.c_void_p]),
+    "xq_engine_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "xq_engine_set_pow_table": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
+    "xq_engine_new_games": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "xq_engine_set_uniforms": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "xq_engine_set_roots": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "xq_engine_search_round": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "xq_engine_eval_hashnet": (C.c_int, [C.c_void_p, C.c_int]),
+    "xq_engine_end_search": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "xq_engine_play_move": (C.c_int, [C.c_void_p]),
+    "xq_engine_finalize": (C.c_int, [C.c_void_p]),
+    "xq_engine_active_games": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "xq_engine_priors_ptr": (C.c_void_p, [C.c_void_p]),
+    "xq_engine_values_ptr": (C.c_void_p, [C.c_void_p]),
+    "xq_engine_rounds_per_move": (C.c_int, [C.c_void_p]),
+    "xq_engine_read_leaves": (C.c_int, [C.c_void_p] * 6),
+    "xq_engine_write_priors": (C.c_int, [C.c_void_p] * 3),
+    "xq_engine_read_root_visits": (C.c_int, [C.c_void_p] * 4),
+    "xq_engine_read_games": (C.c_int, [C.c_void_p] * 8),
+    "xq_engine_read_samples": (C.c_int, [C.c_void_p] * 9),
+    "xq_engine_pack_samples": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "xq_engine_profile": (C.c_int, [C.c_void_p, C.c_int]),
+    "xq_engine_profile_read": (C.c_int, [C.c_void_p] * 5),
+}
+
+EXPORTS = sorted(_SIGNATURES)
+
+
+def lib():
+    """Load libxq_hip.so; raises XqError when it has not been built (no silent fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise XqError("libxq_hip.so is not built (%s): run `python -c 'import __graft_entry__ as g; g.build()'`; "
+                          "the HIP path has no CPU fallback" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = lib().xq_last_error()
+        raise XqError("libxq_hip error %d: %s" % (rc, msg.decode() if msg else "?"))
+
+
+def ptr(a):
+    """numpy array -> void* (None passes NULL)."""
+    return None if a is None else a.ctypes.data_as(C.c_void_p)

@@ -1,0 +1,206 @@
+"""Host mirror of the reference's rules engine, class ChineseChess (chess_env.py:9-768).
+
+Same public surface and attribute names; every rules computation goes through the C ABI of the
+HIP library (include/xq_selfplay.h, batch of one) — there is no Python or CPU implementation
+behind it.  Attributes stay live NumPy / Python objects because callers mutate them directly
+(SURVEY.md §8b "Ownership"): the state is re-packed on every call, so stale king caches behave
+exactly as in the reference (Appendix A6).
+"""
+import numpy as np
+
+from . import _lib
+from .config import BOARD_SIZE, BOARD_WIDTH, PIECES
+
+_REASON_TERMINAL_INT = {1: 100, 2: 200, 3: 0, 4: 0, 5: 100, 6: -10, 7: -10, 8: -2}
+
+
+def decode_move(m):
+    f, t = divmod(int(m), 90)
+    return (f // 9, f % 9, t // 9, t % 9)
+
+
+def encode_move(move):
+    fr, fc, tr, tc = (int(x) for x in move)
+    return (fr * 9 + fc) * 90 + tr * 9 + tc
+
+
+def _sq(pos):
+    return _lib.NO_KING if pos is None else int(pos[0]) * 9 + int(pos[1])
+
+
+def _pos(sq):
+    return None if sq < 0 else (int(sq) // 9, int(sq) % 9)
+
+
+def format_end_reason(code, side, count):
+    """The reference's f-strings (chess_env.py:297,359,366,373,381,389,397,404)."""
+    name = "红方" if side == 1 else "黑方"
+    if code == 1:
+        return f"{name}吃掉对方将帅"
+    if code == 2:
+        return f"将死{name}"
+    if code == 3:
+        return "三次重复局面判和"
+    if code == 4:
+        return "50回合无吃子判和"
+    if code == 5:
+        return f"困毙{name}"
+    if code == 6:
+        return f"长将判负({name})"
+    if code == 7:
+        return f"长捉判负({name})"
+    if code == 8:
+        return f"超过{count}步判和"
+    return None
+
+
+class ChineseChess:
+    def __init__(self):
+        self.reset()
+
+    def reset(self):
+        """chess_env.py:14-67"""
+        self.board = np.zeros((BOARD_SIZE, BOARD_WIDTH), dtype=np.int8)
+        self.position_history = []
+        self.no_capture_count = 0
+        self.check_history = []
+        self.chase_history = []
+        self.consecutive_checks = 0
+        self.red_king_pos = None
+        self.black_king_pos = None
+        self.end_reason = None
+        back = ['ROOK', 'KNIGHT', 'BISHOP', 'ADVISOR', 'KING', 'ADVISOR', 'BISHOP', 'KNIGHT', 'ROOK']
+        for c, name in enumerate(back):
+            self.board[9, c] = PIECES['R_' + name]
+            self.board[0, c] = PIECES['B_' + name]
+        self.red_king_pos = (9, 4)
+        self.black_king_pos = (0, 4)
+        self.board[7, 1] = self.board[7, 7] = PIECES['R_CANNON']
+        self.board[2, 1] = self.board[2, 7] = PIECES['B_CANNON']
+        for i in [0, 2, 4, 6, 8]:
+            self.board[6, i] = PIECES['R_PAWN']
+            self.board[3, i] = PIECES['B_PAWN']
+        self.current_player = 1
+        self.move_count = 0
+        self.winner = None
+        self.end_reason = None
+        return self.get_state()
+
+    def get_state(self):
+        """chess_env.py:69-74"""
+        return self.board.copy(), self.current_player
+
+    # ---- packing helpers -------------------------------------------------------------
+    def _board_bytes(self):
+        return np.ascontiguousarray(self.board, dtype=np.int8).reshape(1, 90).copy()
+
+    def _scalars(self):
+        one = lambda v: np.array([v], dtype=np.int32)
+        return one(self.current_player), one(_sq(self.red_king_pos)), one(_sq(self.black_king_pos))
+
+    def get_legal_moves(self):
+        """chess_env.py:76-121 (order included) via xq_rules_legal_moves."""
+        L = _lib.lib()
+        b = self._board_bytes()
+        player, rk, bk = self._scalars()
+        moves = np.zeros((1, _lib.MAX_MOVES), dtype=np.uint16)
+        count = np.zeros(1, dtype=np.int32)
+        _lib.check(L.xq_rules_legal_moves(1, _lib.ptr(b), _lib.ptr(player), _lib.ptr(rk), _lib.ptr(bk),
+                                           _lib.ptr(moves), _lib.ptr(count)))
+        return [decode_move(m) for m in moves[0, :count[0]]]
+
+    def make_move(self, move):
+        """chess_env.py:253-406 via xq_rules_make_move.  Returns (state, reward, done)."""
+        L = _lib.lib()
+        b = self._board_bytes()
+        st = np.zeros((1, _lib.STATE_WORDS), dtype=np.int32)
+        st[0, _lib.S_PLAYER] = self.current_player
+        st[0, _lib.S_MOVE_COUNT] = self.move_count
+        st[0, _lib.S_WINNER] = _lib.WINNER_NONE if self.winner is None else self.winner
+        st[0, _lib.S_RED_KING] = _sq(self.red_king_pos)
+        st[0, _lib.S_BLACK_KING] = _sq(self.black_king_pos)
+        st[0, _lib.S_NO_CAPTURE] = self.no_capture_count
+        st[0, _lib.S_CONSEC_CHECKS] = self.consecutive_checks
+        nh, ncheck = len(self.position_history), len(self.check_history)
+        stride = max(nh, ncheck, 1)
+        ph = np.zeros((1, stride), dtype=np.uint64)
+        ch = np.zeros((1, stride), dtype=np.uint8)
+        if nh:
+            ph[0, :nh] = np.array([int(h) & 0xFFFFFFFFFFFFFFFF for h in self.position_history], dtype=np.uint64)
+        if ncheck:
+            ch[0, :ncheck] = np.array([1 if c else 0 for c in self.check_history], dtype=np.uint8)
+        mv = np.array([encode_move(move)], dtype=np.int32)
+        n_hist, n_chk = np.array([nh], np.int32), np.array([ncheck], np.int32)
+        reward, done, is_check = np.zeros(1, np.float64), np.zeros(1, np.int32), np.zeros(1, np.int32)
+        key = np.zeros(1, np.uint64)
+        nxt, nxt_n = np.zeros((1, _lib.MAX_MOVES), np.uint16), np.zeros(1, np.int32)
+        _lib.check(L.xq_rules_make_move(1, _lib.ptr(b), _lib.ptr(st), _lib.ptr(mv), _lib.ptr(ph), _lib.ptr(n_hist),
+                                         _lib.ptr(ch), _lib.ptr(n_chk), stride, _lib.ptr(reward), _lib.ptr(done),
+                                         _lib.ptr(is_check), _lib.ptr(key), _lib.ptr(nxt), _lib.ptr(nxt_n)))
+        self.board = b.reshape(BOARD_SIZE, BOARD_WIDTH).copy()
+        self.current_player = int(st[0, _lib.S_PLAYER])
+        self.move_count = int(st[0, _lib.S_MOVE_COUNT])
+        w = int(st[0, _lib.S_WINNER])
+        self.winner = None if w == _lib.WINNER_NONE else w
+        self.red_king_pos = _pos(st[0, _lib.S_RED_KING])
+        self.black_king_pos = _pos(st[0, _lib.S_BLACK_KING])
+        self.no_capture_count = int(st[0, _lib.S_NO_CAPTURE])
+        self.consecutive_checks = int(st[0, _lib.S_CONSEC_CHECKS])
+        self.position_history.append(int(key[0]))
+        self.check_history.append(bool(is_check[0]))
+        self.chase_history.append([])   # dead output in the reference (chess_env.py:345,674): kept for len()
+        r = float(reward[0])
+        if done[0]:
+            code = int(st[0, _lib.S_REASON])
+            self.end_reason = format_end_reason(code, int(st[0, _lib.S_REASON_SIDE]), int(st[0, _lib.S_REASON_COUNT]))
+            r = _REASON_TERMINAL_INT.get(code, r)        # terminal overrides are Python ints (A16)
+        return self.get_state(), r, bool(done[0])
+
+    # ---- predicates the reference's own tests call -------------------------------------
+    def _query(self):
+        L = _lib.lib()
+        b = self._board_bytes()
+        player, rk, bk = self._scalars()
+        a, c, f = (np.zeros(1, np.int32) for _ in range(3))
+        _lib.check(L.xq_rules_query(1, _lib.ptr(b), _lib.ptr(player), _lib.ptr(rk), _lib.ptr(bk),
+                                     _lib.ptr(a), _lib.ptr(c), _lib.ptr(f)))
+        return bool(a[0]), bool(c[0]), bool(f[0])
+
+    def _is_in_check(self, player):
+        """chess_env.py:506-548"""
+        red, black, _ = self._query()
+        return red if player == 1 else black
+
+    def _are_kings_facing(self):
+        """chess_env.py:466-495"""
+        return self._query()[2]
+
+    def _check_perpetual_check(self):
+        """chess_env.py:646-662 (host logic on the public list)"""
+        if len(self.check_history) < 12:
+            return False
+        return sum(1 for c in self.check_history[-12:] if c) >= 10
+
+    def _check_perpetual_chase(self):
+        """chess_env.py:664-674: disabled in the reference"""
+        return False
+
+    def _check_draw_by_fifty_moves(self):
+        """chess_env.py:607-612"""
+        return self.no_capture_count >= 100
+
+    def render(self):
+        """chess_env.py:408-429"""
+        names = {0: '·', 1: '帅', 2: '士', 3: '相', 4: '马', 5: '车', 6: '炮', 7: '兵',
+                 -1: '将', -2: '士', -3: '象', -4: '马', -5: '车', -6: '炮', -7: '卒'}
+        print("\n  ", end="")
+        for i in range(BOARD_WIDTH):
+            print(f"{i} ", end="")
+        print()
+        for r in range(BOARD_SIZE):
+            print(f"{r} ", end="")
+            for c in range(BOARD_WIDTH):
+                print(names[int(self.board[r, c])], end=" ")
+            print()
+        print(f"\n当前: {'红方' if self.current_player == 1 else '黑方'}")
+        print(f"步数: {self.move_count}")

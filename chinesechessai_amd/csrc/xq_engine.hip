@@ -1,0 +1,1353 @@
+// xq_engine.hip — tree + rules kernels and the C ABI of the batched self-play engine (gfx950).
+//
+// Execution model: grid = G workgroups of ONE wavefront (64 lanes); workgroup g owns game g for
+// the whole launch, so every tree update is wave-private (ordered fp64 adds, no atomics) and the
+// 90-byte board plus move buffers live in LDS.  State between launches stays in HBM as SoA:
+// nibble-packed boards (48 B), 16-byte scalar records, a flat per-game node arena
+// (N:u32, W:f64, P:f32, move:u16, first_child:u16, n_child:u8, flags:u8) that is reset every ply
+// because the reference never reuses its tree (self_play.py:98).
+//
+// Kernels (all wave-per-game):
+//   k_new_games     reset + first root move list                         chess_env.py:14-67
+//   k_set_roots     caller-provided root states (MCTS.search on an env)  self_play.py:156-175
+//   k_search_round  [consume evaluator output of round r-1] + the sims of round r on the frozen
+//                   tree, terminal leaves backed up in place, <= 1 pending leaf per game written
+//                   with its network planes                              self_play.py:103-148
+//   k_hashnet       exact dyadic evaluator for parity tests              SURVEY.md Appendix B
+//   k_end_search    consume the last round                               self_play.py:146-154
+//   k_play_move     visits -> pi -> np.random.choice -> make_move        self_play.py:219-256
+//   k_finalize      z table                                              self_play.py:259-310
+//   k_rules_*       batch entry points on caller boards (host mirror of ChineseChess)
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (float results are part of the
+// parity contract: PUCT is float32 stepwise, W is float64, rewards/z are float64).
+#include "xq_device.hpp"
+#include "../../include/xq_selfplay.h"
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+using namespace xq;
+
+// ------------------------------------------------------------------------------------------
+// device-side data structures
+// ------------------------------------------------------------------------------------------
+struct __align__(16) GameS {
+    int8_t  side;
+    uint8_t move_count;
+    int8_t  winner;
+    uint8_t reason;
+    int8_t  reason_side;
+    uint8_t reason_count;
+    int8_t  rk, bk;
+    uint8_t nocap, cchk, n_hist, n_root;
+    uint8_t done, n_samples, error, n_plies;
+};
+static_assert(sizeof(GameS) == 16, "GameS must be 16 bytes");
+static_assert(sizeof(xq_sample_record) == 576, "xq_sample_record layout is part of the ABI");
+
+enum : int { F_TERM = 2, F_VAL_NEG = 4, F_VAL_POS = 8, F_CHECK = 16 };
+enum : int { PATH_CAP = 72, LEAF_NONE = 0xFFFF };
+
+struct Eng {
+    int G, ncap, sims, leaf_batch, nrounds, max_moves, opponent_mode, want_check;
+    double temperature;
+    uint32_t *board;          // [G][12]
+    GameS    *gs;             // [G]
+    uint64_t *pos_hist;       // [G][PATH_CAP]
+    uint8_t  *chk_hist;       // [G][PATH_CAP]
+    uint16_t *root_moves;     // [G][128]
+    double   *uniforms;       // [G][70]
+    // node arena, [G][ncap] each
+    uint32_t *nN; double *nW; float *nP; uint16_t *nMove; uint16_t *nFirst; uint8_t *nNc; uint8_t *nFlags;
+    uint32_t *n_nodes;        // [G]
+    // pending leaf per game
+    uint16_t *leaf_node; uint8_t *leaf_mult; uint8_t *leaf_n; uint8_t *leaf_depth;
+    uint16_t *leaf_moves;     // [G][128]
+    uint16_t *leaf_path;      // [G][PATH_CAP]
+    uint32_t *leaf_board;     // [G][12]
+    int8_t   *leaf_side;      // [G]
+    float    *priors;         // [G][128]
+    double   *values;         // [G]
+    // samples, [G][70]
+    uint32_t *s_board; int8_t *s_player; uint8_t *s_n; uint16_t *s_moves; uint16_t *s_counts; double *s_z;
+    double   *step_reward; uint16_t *t_move;
+    const double *pow_table; int pow_n;
+};
+
+struct __align__(16) WaveLds {
+    int8_t   root_bd[96];
+    int8_t   bd[96];
+    uint16_t cand[128];
+    uint16_t legal[128];
+    uint8_t  own_sq[32];
+    uint16_t path_node[PATH_CAP];
+    uint16_t path_move[PATH_CAP];
+    uint64_t path_key[PATH_CAP];
+    uint8_t  path_chk[PATH_CAP];
+    double   fbuf[128];
+    int      ibuf[128];
+};
+
+__device__ __forceinline__ void mem_fence_wave()
+{
+    // tree arrays are written and re-read by different lanes of the same wave
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+}
+
+__device__ __forceinline__ GameS load_gs(const GameS *p)
+{
+    union { uint4 u; GameS g; } x;
+    x.u = *reinterpret_cast<const uint4 *>(p);
+    return x.g;
+}
+__device__ __forceinline__ void store_gs(GameS *p, const GameS &g)
+{
+    union { uint4 u; GameS g; } x;
+    x.g = g;
+    if (XQ_LANE == 0) *reinterpret_cast<uint4 *>(p) = x.u;
+}
+
+__device__ __forceinline__ MState to_mstate(const GameS &g)
+{
+    MState s;
+    s.side = g.side; s.move_count = g.move_count; s.winner = g.winner; s.reason = g.reason;
+    s.reason_side = g.reason_side; s.reason_count = g.reason_count; s.rk = g.rk; s.bk = g.bk;
+    s.nocap = g.nocap; s.cchk = g.cchk;
+    return s;
+}
+__device__ __forceinline__ void from_mstate(GameS &g, const MState &s)
+{
+    g.side = (int8_t)s.side; g.move_count = (uint8_t)s.move_count; g.winner = (int8_t)s.winner;
+    g.reason = (uint8_t)s.reason; g.reason_side = (int8_t)s.reason_side; g.reason_count = (uint8_t)s.reason_count;
+    g.rk = (int8_t)s.rk; g.bk = (int8_t)s.bk; g.nocap = (uint8_t)(s.nocap > 255 ? 255 : s.nocap);
+    g.cchk = (uint8_t)(s.cchk > 255 ? 255 : s.cchk);
+}
+
+// ---- history adapters for wave_make_move -------------------------------------------------
+struct HistPath {               // in-search env: starts empty (self_play.py:173-174)
+    uint64_t *keys; uint8_t *chk; int n; bool keys_on;
+    __device__ bool want_keys() const { return keys_on; }
+    __device__ void push(uint64_t key, int c)
+    {
+        if (XQ_LANE == 0 && n < PATH_CAP) { keys[n] = key; chk[n] = (uint8_t)c; }
+        n++;
+        wave_sync();
+    }
+    __device__ int count_key(uint64_t key) const
+    {
+        int cnt = 0;
+        for (int b = 0; b < n && b < PATH_CAP; b += 64) {
+            int i = b + XQ_LANE;
+            cnt += __builtin_popcountll(__ballot(i < n && i < PATH_CAP && keys[i] == key));
+        }
+        return cnt;
+    }
+    __device__ bool perpetual() const
+    {
+        if (n < 12) return false;
+        int i = n - 12 + XQ_LANE;
+        return __builtin_popcountll(__ballot(XQ_LANE < 12 && i < PATH_CAP && chk[i] != 0)) >= 10;
+    }
+};
+
+struct HistGlobal {             // real env: history kept by the caller (HBM), new entry returned
+    const uint64_t *keys; const uint8_t *chk; int n_keys, n_chk;
+    uint64_t new_key; int new_chk;
+    __device__ bool want_keys() const { return true; }
+    __device__ void push(uint64_t key, int c) { new_key = key; new_chk = c; }
+    __device__ int count_key(uint64_t key) const
+    {
+        int cnt = (new_key == key) ? 1 : 0;
+        for (int b = 0; b < n_keys; b += 64) {
+            int i = b + XQ_LANE;
+            cnt += __builtin_popcountll(__ballot(i < n_keys && keys[i] == key));
+        }
+        return cnt;
+    }
+    __device__ bool perpetual() const
+    {
+        if (n_chk + 1 < 12) return false;
+        int i = n_chk - 11 + XQ_LANE;            // last 11 stored entries + the new one
+        int c = __builtin_popcountll(__ballot(XQ_LANE < 11 && chk[i] != 0));
+        return c + (new_chk ? 1 : 0) >= 10;
+    }
+};
+
+// ---- network input planes (neural_network.py:128-146) ------------------------------------
+__device__ __forceinline__ float plane_value(const int8_t *bd, int side, int c, int s)
+{
+    if (c == 14) return side == 1 ? 1.0f : 0.0f;
+    int code = c < 7 ? c + 1 : -(c - 6);
+    return bd[s] == code ? 1.0f : 0.0f;
+}
+
+__device__ void write_planes(const int8_t *bd, int side, void *planes, int fmt, int g)
+{
+    const int lane = XQ_LANE;
+    if (fmt == XQ_PLANES_NCHW_F32) {
+        float *o = reinterpret_cast<float *>(planes) + (size_t)g * 1350;
+        for (int e = lane; e < 1350; e += 64) o[e] = plane_value(bd, side, e / 90, e % 90);
+    } else if (fmt == XQ_PLANES_NCHW_BF16) {
+        uint32_t *o = reinterpret_cast<uint32_t *>(planes) + (size_t)g * 675;
+        for (int i = lane; i < 675; i += 64) {
+            int e0 = 2 * i, e1 = 2 * i + 1;
+            uint32_t lo = plane_value(bd, side, e0 / 90, e0 % 90) != 0.0f ? 0x3F80u : 0u;
+            uint32_t hi = plane_value(bd, side, e1 / 90, e1 % 90) != 0.0f ? 0x3F80u : 0u;
+            o[i] = lo | (hi << 16);
+        }
+    } else if (fmt == XQ_PLANES_NHWC16_BF16) {
+        uint4 *o = reinterpret_cast<uint4 *>(planes) + (size_t)g * 180;     // 90 squares x 32 B
+        for (int s = lane; s < 90; s += 64) {
+            int p = bd[s];
+            int ch = p > 0 ? p - 1 : (p < 0 ? 6 - p : -1);
+            uint32_t w[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+            if (ch >= 0) w[ch >> 1] = 0x3F80u << ((ch & 1) * 16);
+            if (side == 1) w[7] |= 0x3F80u;                                 // channel 14
+            o[2 * s] = make_uint4(w[0], w[1], w[2], w[3]);
+            o[2 * s + 1] = make_uint4(w[4], w[5], w[6], w[7]);
+        }
+    }
+}
+
+__device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
+
+// ---- tree primitives ---------------------------------------------------------------------
+struct Tree {
+    uint32_t *N; double *W; float *P; uint16_t *mv; uint16_t *first; uint8_t *nc; uint8_t *fl;
+};
+__device__ __forceinline__ Tree tree_of(const Eng &E, int g)
+{
+    size_t o = (size_t)g * E.ncap;
+    return Tree{ E.nN + o, E.nW + o, E.nP + o, E.nMove + o, E.nFirst + o, E.nNc + o, E.nFlags + o };
+}
+
+// self_play.py:40-59 — float32 stepwise PUCT (NumPy >= 2 scalar rules), first maximum wins
+__device__ int select_child(const Tree &T, int node)
+{
+    const int lane = XQ_LANE;
+    const int first = T.first[node], nc = T.nc[node];
+    const float sq = (float)sqrt((double)T.N[node]);
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int c = lane; c < nc; c += 64) {
+        const uint32_t n = T.N[first + c];
+        const double w = T.W[first + c];
+        const float p = T.P[first + c];
+        float q = n ? (float)(w / (double)n) : 0.0f;
+        float t = 1.5f * p;
+        t = t * sq;
+        t = t / (float)(1u + n);
+        float s = q + t;
+        if (s > best) { best = s; bi = c; }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        float os = __shfl_xor(best, d, 64);
+        int oi = __shfl_xor(bi, d, 64);
+        if (os > best || (os == best && oi < bi)) { best = os; bi = oi; }
+    }
+    return first + uni(bi);
+}
+
+// self_play.py:70-80: `mult` sequential updates of value v at the node on level `depth`
+// (levels: 0 = root, i = path_node[i-1]); every ancestor alternates the sign.
+__device__ void backup(const Tree &T, const uint16_t *path_node, int depth, double v, int mult)
+{
+    const int lane = XQ_LANE;
+    if (lane <= depth) {
+        const int x = lane == 0 ? 0 : path_node[lane - 1];
+        const double sv = ((depth - lane) & 1) ? -v : v;
+        double w = T.W[x];
+        for (int i = 0; i < mult; i++) w += sv;
+        T.W[x] = w;
+        T.N[x] += (uint32_t)mult;
+    }
+    mem_fence_wave();
+}
+
+// self_play.py:61-68 + 146-148: expand the pending leaf with its priors and apply its backups
+__device__ void consume_eval(const Eng &E, int g, WaveLds &L, const Tree &T, int eval_kind,
+                             const void *ev_a, const void *ev_v)
+{
+    const int lane = XQ_LANE;
+    const int node = E.leaf_node[g];
+    if (node == LEAF_NONE) return;
+    const int n = E.leaf_n[g], mult = E.leaf_mult[g], depth = E.leaf_depth[g];
+    const uint16_t *lm = E.leaf_moves + (size_t)g * MAXM;
+    double v;
+    float p0 = 0.f, p1 = 0.f;
+    const int m0 = lane < n ? lm[lane] : 0, m1 = lane + 64 < n ? lm[lane + 64] : 0;
+    if (eval_kind == XQ_EVAL_PRIORS) {
+        const float *pr = reinterpret_cast<const float *>(ev_a) + (size_t)g * MAXM;
+        if (lane < n) p0 = pr[lane];
+        if (lane + 64 < n) p1 = pr[lane + 64];
+        v = reinterpret_cast<const double *>(ev_v)[g];
+    } else {
+        // neural_network.py:148-169: gather the legal logits, float32 softmax over them
+        float x0 = -INFINITY, x1 = -INFINITY;
+        if (eval_kind == XQ_EVAL_LOGITS_F32) {
+            const float *lg = reinterpret_cast<const float *>(ev_a) + (size_t)g * XQ_POLICY_SIZE;
+            if (lane < n) x0 = lg[m0];
+            if (lane + 64 < n) x1 = lg[m1];
+            v = (double)reinterpret_cast<const float *>(ev_v)[g];
+        } else {
+            const uint16_t *lg = reinterpret_cast<const uint16_t *>(ev_a) + (size_t)g * XQ_POLICY_SIZE;
+            if (lane < n) x0 = bf16_to_f32(lg[m0]);
+            if (lane + 64 < n) x1 = bf16_to_f32(lg[m1]);
+            v = (double)bf16_to_f32(reinterpret_cast<const uint16_t *>(ev_v)[g]);
+        }
+        float mx = fmaxf(x0, x1);
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d, 64));
+        float e0 = lane < n ? expf(x0 - mx) : 0.f, e1 = lane + 64 < n ? expf(x1 - mx) : 0.f;
+        float sum = e0 + e1;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d, 64);
+        p0 = e0 / sum; p1 = e1 / sum;
+    }
+    const int first = (int)E.n_nodes[g];
+    if (first + n <= E.ncap) {
+        for (int h = 0; h < 2; h++) {
+            int j = lane + 64 * h;
+            if (j < n) {
+                int x = first + j;
+                T.N[x] = 0; T.W[x] = 0.0; T.P[x] = h ? p1 : p0; T.mv[x] = (uint16_t)(h ? m1 : m0);
+                T.first[x] = 0; T.nc[x] = 0; T.fl[x] = 0;
+            }
+        }
+        if (lane == 0) { T.first[node] = (uint16_t)first; T.nc[node] = (uint8_t)n; E.n_nodes[g] = (uint32_t)(first + n); }
+    }
+    if (lane < depth) L.path_node[lane] = E.leaf_path[(size_t)g * PATH_CAP + lane];
+    wave_sync();
+    mem_fence_wave();
+    backup(T, L.path_node, depth, v, mult);
+    if (lane == 0) E.leaf_node[g] = LEAF_NONE;
+}
+
+// ------------------------------------------------------------------------------------------
+// kernels
+// ------------------------------------------------------------------------------------------
+__device__ void init_board(int8_t *bd)
+{
+    const int lane = XQ_LANE;
+    for (int s = lane; s < 96; s += 64) {
+        int p = 0;
+        if (s < 90) {
+            const int r = s / 9, c = s % 9;
+            const int back[9] = { ROOK, KNIGHT, BISHOP, ADVISOR, KING, ADVISOR, BISHOP, KNIGHT, ROOK };
+            if (r == 9) p = back[c];
+            else if (r == 0) p = -back[c];
+            else if (r == 7 && (c == 1 || c == 7)) p = CANNON;
+            else if (r == 2 && (c == 1 || c == 7)) p = -CANNON;
+            else if (r == 6 && (c % 2 == 0)) p = PAWN;
+            else if (r == 3 && (c % 2 == 0)) p = -PAWN;
+        }
+        bd[s] = (int8_t)p;
+    }
+}
+
+__global__ __launch_bounds__(64) void k_new_games(Eng E)
+{
+    __shared__ WaveLds L;
+    const int g = blockIdx.x, lane = XQ_LANE;
+    init_board(L.bd);
+    wave_sync();
+    BoardView v = load_view(L.bd);
+    const int rk = 9 * 9 + 4, bk = 4;
+    const int n = wave_movegen(L.bd, v, 1, rk, bk, L.cand, L.legal, L.own_sq);
+    for (int j = lane; j < n; j += 64) E.root_moves[(size_t)g * MAXM + j] = L.legal[j];
+    if (lane < 12) E.board[(size_t)g * 12 + lane] = pack_dword(L.bd, lane);
+    GameS gs;
+    gs.side = 1; gs.move_count = 0; gs.winner = WINNER_NONE; gs.reason = R_NONE; gs.reason_side = 0;
+    gs.reason_count = 0; gs.rk = (int8_t)rk; gs.bk = (int8_t)bk; gs.nocap = 0; gs.cchk = 0; gs.n_hist = 0;
+    gs.n_root = (uint8_t)n; gs.done = 0; gs.n_samples = 0; gs.error = 0; gs.n_plies = 0;
+    store_gs(E.gs + g, gs);
+    if (lane == 0) { E.leaf_node[g] = LEAF_NONE; E.leaf_mult[g] = 0; }
+}
+
+// roots from caller-provided envs (one staged int8 board + int32 state row per game)
+__global__ __launch_bounds__(64) void k_set_roots(Eng E, const int8_t *boards, const int32_t *state)
+{
+    __shared__ WaveLds L;
+    const int g = blockIdx.x, lane = XQ_LANE;
+    for (int s = lane; s < 96; s += 64) L.bd[s] = s < 90 ? boards[(size_t)g * 90 + s] : 0;
+    wave_sync();
+    const int32_t *st = state + (size_t)g * XQ_STATE_WORDS;
+    BoardView v = load_view(L.bd);
+    const int side = st[XQ_S_PLAYER], rk = st[XQ_S_RED_KING], bk = st[XQ_S_BLACK_KING];
+    const int n = wave_movegen(L.bd, v, side, rk, bk, L.cand, L.legal, L.own_sq);
+    for (int j = lane; j < n; j += 64) E.root_moves[(size_t)g * MAXM + j] = L.legal[j];
+    if (lane < 12) E.board[(size_t)g * 12 + lane] = pack_dword(L.bd, lane);
+    GameS gs;
+    gs.side = (int8_t)side; gs.move_count = (uint8_t)st[XQ_S_MOVE_COUNT]; gs.winner = (int8_t)st[XQ_S_WINNER];
+    gs.reason = R_NONE; gs.reason_side = 0; gs.reason_count = 0; gs.rk = (int8_t)rk; gs.bk = (int8_t)bk;
+    gs.nocap = (uint8_t)st[XQ_S_NO_CAPTURE]; gs.cchk = 0; gs.n_hist = 0; gs.n_root = (uint8_t)n;
+    gs.done = (n == 0) ? 1 : 0; gs.n_samples = 0; gs.error = 0; gs.n_plies = 0;
+    store_gs(E.gs + g, gs);
+    if (lane == 0) { E.leaf_node[g] = LEAF_NONE; E.leaf_mult[g] = 0; }
+}
+
+__device__ void record_leaf(const Eng &E, int g, WaveLds &L, const int8_t *bd, int side, int node,
+                            int depth, int mult, const uint16_t *moves, int n, void *planes, int fmt)
+{
+    const int lane = XQ_LANE;
+    for (int j = lane; j < n; j += 64) E.leaf_moves[(size_t)g * MAXM + j] = moves[j];
+    if (lane < depth) E.leaf_path[(size_t)g * PATH_CAP + lane] = L.path_node[lane];
+    if (lane < 12) E.leaf_board[(size_t)g * 12 + lane] = pack_dword(bd, lane);
+    if (lane == 0) {
+        E.leaf_node[g] = (uint16_t)node; E.leaf_mult[g] = (uint8_t)mult; E.leaf_n[g] = (uint8_t)n;
+        E.leaf_depth[g] = (uint8_t)depth; E.leaf_side[g] = (int8_t)side;
+    }
+    if (planes) write_planes(bd, side, planes, fmt, g);
+}
+
+__global__ __launch_bounds__(64) void k_search_round(Eng E, int round, int batch_count, int eval_kind,
+                                                     const void *ev_a, const void *ev_v, void *planes, int fmt)
+{
+    __shared__ WaveLds L;
+    const int g = blockIdx.x, lane = XQ_LANE;
+    const GameS gs = load_gs(E.gs + g);
+    if (gs.done) return;
+    const Tree T = tree_of(E, g);
+
+    if (round == 0) {
+        if (lane == 0) {                             // fresh tree every ply (self_play.py:98)
+            T.N[0] = 0; T.W[0] = 0.0; T.P[0] = 0.f; T.mv[0] = 0; T.first[0] = 0; T.nc[0] = 0; T.fl[0] = 0;
+            E.n_nodes[g] = 1; E.leaf_node[g] = LEAF_NONE;
+        }
+        mem_fence_wave();
+    } else {
+        consume_eval(E, g, L, T, eval_kind, ev_a, ev_v);
+    }
+
+    unpack_to_lds(E.board + (size_t)g * 12, L.root_bd);
+    wave_sync();
+
+    int sims_left = batch_count;
+    while (sims_left > 0) {
+        // ---- select (self_play.py:117-119); the tree is frozen unless a terminal leaf updates it
+        int node = 0, depth = 0;
+        while (T.nc[node] != 0 && depth < PATH_CAP) {
+            const int child = select_child(T, node);
+            if (lane == 0) { L.path_node[depth] = (uint16_t)child; L.path_move[depth] = T.mv[child]; }
+            node = child;
+            depth++;
+        }
+        wave_sync();
+        int flags = T.fl[node];
+        if (!(flags & F_TERM)) {
+            if (node == 0) {
+                // the root is never terminal (the driver checked legal moves, self_play.py:205-208)
+                record_leaf(E, g, L, L.root_bd, gs.side, 0, 0, sims_left, E.root_moves + (size_t)g * MAXM,
+                            gs.n_root, planes, fmt);
+                return;
+            }
+            // ---- replay the path on a copy of the root env (_copy_env, self_play.py:156-175)
+            for (int s = lane; s < 24; s += 64)
+                reinterpret_cast<uint32_t *>(L.bd)[s] = reinterpret_cast<const uint32_t *>(L.root_bd)[s];
+            wave_sync();
+            MState st = to_mstate(gs);
+            st.cchk = 0; st.reason = R_NONE;
+            HistPath hist{ L.path_key, L.path_chk, 0, depth >= 6 };
+            for (int i = 0; i + 1 < depth; i++) {
+                // interior nodes were classified non-terminal when first reached; only the
+                // state that later plies read is replayed (board, caches, counters, history)
+                const int mv = L.path_move[i], from = mv / 90, to = mv % 90;
+                const int captured = L.bd[to], moving = L.bd[from];
+                wave_sync();
+                if (lane == 0) { L.bd[to] = (int8_t)moving; L.bd[from] = 0; }
+                wave_sync();
+                if (moving == KING) st.rk = to; else if (moving == -KING) st.bk = to;
+                if (captured == KING) st.rk = NO_KING; else if (captured == -KING) st.bk = NO_KING;
+                if (captured != 0) st.nocap = 0; else st.nocap += 1;
+                const uint64_t key = hist.keys_on ? position_key(L.bd, st.side == 1 ? 0 : 1) : 0ull;
+                const int chk = (T.fl[L.path_node[i]] & F_CHECK) ? 1 : 0;
+                hist.push(key, chk);
+                st.side = -st.side;
+                st.move_count += 1;
+            }
+            MoveResult mr;
+            if (E.want_check)
+                mr = wave_make_move<false, true>(L.bd, st, L.path_move[depth - 1], hist, L.cand, L.legal, L.own_sq);
+            else
+                mr = wave_make_move<false, false>(L.bd, st, L.path_move[depth - 1], hist, L.cand, L.legal, L.own_sq);
+            flags |= mr.is_check ? F_CHECK : 0;
+            const bool terminal = (mr.n_legal == 0) || (st.winner != WINNER_NONE);     // self_play.py:126
+            if (!terminal) {
+                if (lane == 0) T.fl[node] = (uint8_t)flags;
+                record_leaf(E, g, L, L.bd, st.side, node, depth, sims_left, L.legal, mr.n_legal, planes, fmt);
+                return;
+            }
+            // self_play.py:128-133, value from the side to move at the leaf
+            flags |= F_TERM;
+            if (st.winner == st.side) flags |= F_VAL_POS;
+            else if (st.winner == -st.side) flags |= F_VAL_NEG;
+            if (lane == 0) T.fl[node] = (uint8_t)flags;
+        }
+        const double v = (flags & F_VAL_POS) ? 1.0 : ((flags & F_VAL_NEG) ? -1.0 : 0.0);
+        backup(T, L.path_node, depth, v, 1);                                           // self_play.py:135
+        sims_left--;
+    }
+}
+
+__constant__ uint32_t c_crc_table[256];
+
+__device__ __forceinline__ uint32_t crc_byte(uint32_t crc, uint32_t b)
+{
+    return c_crc_table[(crc ^ b) & 0xffu] ^ (crc >> 8);
+}
+
+// exact dyadic evaluator: priors k/1024, values m/64 from CRC-32
+__global__ __launch_bounds__(64) void k_hashnet(Eng E, int salt)
+{
+    __shared__ WaveLds L;
+    const int g = blockIdx.x, lane = XQ_LANE;
+    if (E.gs[g].done || E.leaf_node[g] == LEAF_NONE) return;
+    unpack_to_lds(E.leaf_board + (size_t)g * 12, L.bd);
+    wave_sync();
+    uint32_t crc = 0xffffffffu;
+    for (int s = 0; s < 90; s++) crc = crc_byte(crc, (uint32_t)(uint8_t)L.bd[s]);
+    crc = crc_byte(crc, (uint32_t)(uint8_t)E.leaf_side[g]);
+    if (salt) crc = crc_byte(crc, (uint32_t)salt & 0xffu);
+    const uint32_t h0 = ~crc;
+    const int n = E.leaf_n[g];
+    for (int j = lane; j < n; j += 64) {
+        const int mv = E.leaf_moves[(size_t)g * MAXM + j], from = mv / 90, to = mv % 90;
+        uint32_t c = ~h0;
+        c = crc_byte(c, from / 9); c = crc_byte(c, from % 9); c = crc_byte(c, to / 9); c = crc_byte(c, to % 9);
+        const uint32_t h = ~c;
+        E.priors[(size_t)g * MAXM + j] = (float)((h >> 8) % 64u + 1u) / 1024.0f;
+    }
+    if (lane == 0) E.values[g] = ((double)((h0 >> 4) % 65u) - 32.0) / 64.0;
+}
+
+__global__ __launch_bounds__(64) void k_end_search(Eng E, int eval_kind, const void *ev_a, const void *ev_v)
+{
+    __shared__ WaveLds L;
+    const int g = blockIdx.x;
+    if (E.gs[g].done) return;
+    const Tree T = tree_of(E, g);
+    consume_eval(E, g, L, T, eval_kind, ev_a, ev_v);
+}
+
+// NumPy float64 add.reduce (pairwise, 8 partial sums; n <= 128)
+__device__ double np_sum(const double *a, int n)
+{
+    if (n < 8) {
+        double res = 0.;
+        for (int i = 0; i < n; i++) res += a[i];
+        return res;
+    }
+    double r0 = a[0], r1 = a[1], r2 = a[2], r3 = a[3], r4 = a[4], r5 = a[5], r6 = a[6], r7 = a[7];
+    int i;
+    for (i = 8; i < n - (n % 8); i += 8) {
+        r0 += a[i]; r1 += a[i + 1]; r2 += a[i + 2]; r3 += a[i + 3];
+        r4 += a[i + 4]; r5 += a[i + 5]; r6 += a[i + 6]; r7 += a[i + 7];
+    }
+    double res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+    for (; i < n; i++) res += a[i];
+    return res;
+}
+
+// self_play.py:219-256 for every game: pi from root visits, sample record, np.random.choice on the
+// game's private MT19937 stream, make_move, and the next root's move list.
+__global__ __launch_bounds__(64) void k_play_move(Eng E)
+{
+    __shared__ WaveLds L;
+    const int g = blockIdx.x, lane = XQ_LANE;
+    GameS gs = load_gs(E.gs + g);
+    if (gs.done) return;
+    const Tree T = tree_of(E, g);
+    const int nc = T.nc[0], first = T.first[0];
+    if (nc == 0) { gs.done = 1; store_gs(E.gs + g, gs); return; }       // self_play.py:216-217
+
+    for (int j = lane; j < nc; j += 64) L.ibuf[j] = (int)T.N[first + j];
+    unpack_to_lds(E.board + (size_t)g * 12, L.bd);
+    wave_sync();
+
+    // sample record (self_play.py:234-239)
+    const bool store = (gs.side == 1) || !E.opponent_mode;
+    if (store) {
+        const size_t si = (size_t)g * XQ_MAX_PLIES + gs.n_samples;
+        if (lane < 12) E.s_board[si * 12 + lane] = E.board[(size_t)g * 12 + lane];
+        for (int j = lane; j < MAXM; j += 64) {
+            E.s_moves[si * MAXM + j] = j < nc ? T.mv[first + j] : 0;
+            E.s_counts[si * MAXM + j] = j < nc ? (uint16_t)L.ibuf[j] : 0;
+        }
+        if (lane == 0) { E.s_player[si] = gs.side; E.s_n[si] = (uint8_t)nc; }
+    }
+
+    // move probabilities and np.random.choice (serial float64, order matters)
+    int pick = -1;
+    if (lane == 0) {
+        if (E.temperature < 0.01) {                                      // self_play.py:224-227
+            int am = 0;
+            for (int j = 1; j < nc; j++) if (L.ibuf[j] > L.ibuf[am]) am = j;
+            for (int j = 0; j < nc; j++) L.fbuf[j] = 0.0;
+            L.fbuf[am] = 1.0;
+        } else {                                                         // self_play.py:230-231
+            for (int j = 0; j < nc; j++) {
+                const int c = L.ibuf[j];
+                L.fbuf[j] = (E.pow_table && c < E.pow_n) ? E.pow_table[c] : (double)c;
+            }
+            const double sum = np_sum(L.fbuf, nc);
+            for (int j = 0; j < nc; j++) L.fbuf[j] = L.fbuf[j] / sum;
+        }
+        // RandomState.choice: cdf = p.cumsum(); cdf /= cdf[-1]; searchsorted(u, 'right')
+        bool nan = false;
+        double acc = 0;
+        for (int j = 0; j < nc; j++) { nan |= (L.fbuf[j] != L.fbuf[j]); acc += L.fbuf[j]; L.fbuf[j] = acc; }
+        if (!nan) {
+            const double last = L.fbuf[nc - 1];
+            const double u = E.uniforms[(size_t)g * XQ_MAX_PLIES + gs.n_plies];
+            int lo = 0, hi = nc;
+            while (lo < hi) {
+                int mid = lo + ((hi - lo) >> 1);
+                if (L.fbuf[mid] / last <= u) lo = mid + 1; else hi = mid;
+            }
+            pick = lo < nc ? lo : nc - 1;
+        }
+    }
+    pick = uni(pick);
+    if (pick < 0) {                      // ValueError: probabilities contain NaN (sims <= leaf_batch)
+        gs.error = 1; gs.done = 1;
+        store_gs(E.gs + g, gs);
+        return;
+    }
+    const int move = T.mv[first + pick];
+
+    MState st = to_mstate(gs);
+    HistGlobal hist{ E.pos_hist + (size_t)g * PATH_CAP, E.chk_hist + (size_t)g * PATH_CAP, gs.n_hist, gs.n_hist, 0ull, 0 };
+    MoveResult mr = wave_make_move<true, true>(L.bd, st, move, hist, L.cand, L.legal, L.own_sq);
+    from_mstate(gs, st);
+    if (lane == 0) {
+        if (gs.n_hist < PATH_CAP) {
+            E.pos_hist[(size_t)g * PATH_CAP + gs.n_hist] = hist.new_key;
+            E.chk_hist[(size_t)g * PATH_CAP + gs.n_hist] = (uint8_t)hist.new_chk;
+        }
+        E.step_reward[(size_t)g * XQ_MAX_PLIES + gs.n_plies] = mr.reward;
+        E.t_move[(size_t)g * XQ_MAX_PLIES + gs.n_plies] = (uint16_t)move;
+    }
+    gs.n_hist += 1;
+    gs.n_plies += 1;
+    if (store) gs.n_samples += 1;
+    if (lane < 12) E.board[(size_t)g * 12 + lane] = pack_dword(L.bd, lane);
+    for (int j = lane; j < mr.n_legal; j += 64) E.root_moves[(size_t)g * MAXM + j] = L.legal[j];
+    gs.n_root = (uint8_t)mr.n_legal;
+    // self_play.py:203,205-208,255-256: stop on done, on MAX_MOVES, or when nothing is legal
+    gs.done = (mr.done || gs.n_plies >= E.max_moves || mr.n_legal == 0) ? 1 : 0;
+    store_gs(E.gs + g, gs);
+}
+
+// self_play.py:259-310
+__global__ __launch_bounds__(64) void k_finalize(Eng E)
+{
+    const int g = blockIdx.x, lane = XQ_LANE;
+    const GameS gs = load_gs(E.gs + g);
+    const int winner = gs.winner == WINNER_NONE ? 0 : gs.winner;
+    const int len = gs.n_samples;
+    for (int i = lane; i < len; i += 64) {
+        const size_t si = (size_t)g * XQ_MAX_PLIES + i;
+        const int player = E.s_player[si];
+        double fr;
+        if (winner == 0) fr = len >= 60 ? (player == 1 ? -0.15 : 0.05) : (player == 1 ? -0.1 : 0.1);
+        else if (winner == player) fr = 1.0 + (len <= 30 ? 0.5 : len <= 50 ? 0.3 : len <= 70 ? 0.1 : 0.0);
+        else fr = len >= 60 ? -1.2 : -1.0;
+        const double imm = i < gs.n_plies ? E.step_reward[si] : 0.0;   // indexed by sample index (A14 note)
+        const double scaled = imm * 0.01;
+        E.s_z[si] = fr + scaled;
+    }
+}
+
+__global__ __launch_bounds__(64) void k_pack_samples(Eng E, xq_sample_record *rec)
+{
+    const int g = blockIdx.x, lane = XQ_LANE;
+    const GameS gs = load_gs(E.gs + g);
+    for (int i = 0; i < XQ_MAX_PLIES; i++) {
+        const size_t si = (size_t)g * XQ_MAX_PLIES + i;
+        xq_sample_record *r = rec + si;
+        const bool valid = i < gs.n_samples;
+        if (lane < 12) r->board[lane] = valid ? E.s_board[si * 12 + lane] : 0u;
+        for (int j = lane; j < MAXM; j += 64) {
+            r->moves[j] = valid ? E.s_moves[si * MAXM + j] : 0;
+            r->counts[j] = valid ? E.s_counts[si * MAXM + j] : 0;
+        }
+        if (lane == 0) {
+            r->z = valid ? E.s_z[si] : 0.0;
+            r->player = valid ? E.s_player[si] : 0;
+            r->n_moves = valid ? E.s_n[si] : 0;
+            r->valid = valid ? 1 : 0;
+            r->pad = 0; r->pad2 = 0;
+            r->chosen = valid ? E.t_move[si] : 0;
+        }
+    }
+}
+
+__global__ void k_count_active(const GameS *gs, int G, int *out)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int a = (i < G && !gs[i].done) ? 1 : 0;
+    unsigned long long m = __ballot(a);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(out, __builtin_popcountll(m));
+}
+
+// ---- rules entry points on caller boards -------------------------------------------------
+__global__ __launch_bounds__(64) void k_rules_legal(int n, const int8_t *boards, const int32_t *player,
+                                                    const int32_t *rk, const int32_t *bk,
+                                                    uint16_t *moves, int32_t *counts)
+{
+    __shared__ WaveLds L;
+    const int g = blockIdx.x, lane = XQ_LANE;
+    for (int s = lane; s < 96; s += 64) L.bd[s] = s < 90 ? boards[(size_t)g * 90 + s] : 0;
+    wave_sync();
+    BoardView v = load_view(L.bd);
+    const int cnt = wave_movegen(L.bd, v, player[g], rk[g], bk[g], L.cand, L.legal, L.own_sq);
+    for (int j = lane; j < cnt; j += 64) moves[(size_t)g * MAXM + j] = L.legal[j];
+    if (lane == 0) counts[g] = cnt;
+}
+
+__global__ __launch_bounds__(64) void k_rules_query(int n, const int8_t *boards, const int32_t *player,
+                                                    const int32_t *rk, const int32_t *bk,
+                                                    int32_t *chk_red, int32_t *chk_black, int32_t *facing)
+{
+    __shared__ WaveLds L;
+    const int g = blockIdx.x, lane = XQ_LANE;
+    for (int s = lane; s < 96; s += 64) L.bd[s] = s < 90 ? boards[(size_t)g * 90 + s] : 0;
+    wave_sync();
+    BoardView v = load_view(L.bd);
+    const bool cr = in_check(v, 1, player[g], rk[g], bk[g]);
+    const bool cb = in_check(v, -1, player[g], rk[g], bk[g]);
+    const bool f = kings_facing(rk[g], bk[g], v.occC);
+    if (lane == 0) { chk_red[g] = cr; chk_black[g] = cb; facing[g] = f; }
+}
+
+__global__ __launch_bounds__(64) void k_rules_make_move(int n, int8_t *boards, int32_t *state, const int32_t *move,
+                                                        const uint64_t *pos_hist, const int32_t *n_hist,
+                                                        const uint8_t *chk_hist, const int32_t *n_chk, int stride,
+                                                        double *reward, int32_t *done, int32_t *is_check,
+                                                        uint64_t *key_out, uint16_t *next_moves, int32_t *next_count)
+{
+    __shared__ WaveLds L;
+    const int g = blockIdx.x, lane = XQ_LANE;
+    for (int s = lane; s < 96; s += 64) L.bd[s] = s < 90 ? boards[(size_t)g * 90 + s] : 0;
+    wave_sync();
+    int32_t *sw = state + (size_t)g * XQ_STATE_WORDS;
+    MState st;
+    st.side = sw[XQ_S_PLAYER]; st.move_count = sw[XQ_S_MOVE_COUNT]; st.winner = sw[XQ_S_WINNER];
+    st.rk = sw[XQ_S_RED_KING]; st.bk = sw[XQ_S_BLACK_KING]; st.nocap = sw[XQ_S_NO_CAPTURE];
+    st.cchk = sw[XQ_S_CONSEC_CHECKS]; st.reason = sw[XQ_S_REASON]; st.reason_side = sw[XQ_S_REASON_SIDE];
+    st.reason_count = sw[XQ_S_REASON_COUNT];
+    HistGlobal hist{ pos_hist + (size_t)g * stride, chk_hist + (size_t)g * stride, n_hist[g], n_chk[g], 0ull, 0 };
+    MoveResult mr = wave_make_move<true, true>(L.bd, st, move[g], hist, L.cand, L.legal, L.own_sq);
+    wave_sync();
+    for (int s = lane; s < 90; s += 64) boards[(size_t)g * 90 + s] = L.bd[s];
+    for (int j = lane; j < mr.n_legal; j += 64) next_moves[(size_t)g * MAXM + j] = L.legal[j];
+    if (lane == 0) {
+        sw[XQ_S_PLAYER] = st.side; sw[XQ_S_MOVE_COUNT] = st.move_count; sw[XQ_S_WINNER] = st.winner;
+        sw[XQ_S_RED_KING] = st.rk; sw[XQ_S_BLACK_KING] = st.bk; sw[XQ_S_NO_CAPTURE] = st.nocap;
+        sw[XQ_S_CONSEC_CHECKS] = st.cchk; sw[XQ_S_REASON] = st.reason; sw[XQ_S_REASON_SIDE] = st.reason_side;
+        sw[XQ_S_REASON_COUNT] = st.reason_count;
+        reward[g] = mr.reward; done[g] = mr.done; is_check[g] = mr.is_check; key_out[g] = hist.new_key;
+        next_count[g] = mr.n_legal;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+
+static int fail(int code, const std::string &msg)
+{
+    g_err = msg;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                         \
+    do {                                                                                     \
+        hipError_t _e = (expr);                                                              \
+        if (_e != hipSuccess)                                                                \
+            return fail(XQ_E_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));        \
+    } while (0)
+
+extern "C" const char *xq_last_error(void) { return g_err.c_str(); }
+
+extern "C" int xq_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" int xq_device_ok(int device)
+{
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, device) != hipSuccess) return 0;
+    return strncmp(p.gcnArchName, "gfx950", 6) == 0 ? 1 : 0;
+}
+
+static bool g_crc_ready[64] = { false };
+
+static int ensure_crc_table(int device)
+{
+    if (device < 0 || device >= 64) return fail(XQ_E_INVALID, "device ordinal out of range");
+    if (g_crc_ready[device]) return 0;
+    uint32_t tab[256];
+    for (uint32_t i = 0; i < 256; i++) {
+        uint32_t c = i;
+        for (int k = 0; k < 8; k++) c = (c & 1) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+        tab[i] = c;
+    }
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_crc_table), tab, sizeof tab));
+    g_crc_ready[device] = true;
+    return 0;
+}
+
+// RAII-less device buffer helper: every rules call stages through temporary buffers
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 4) == hipSuccess ? 0 : -1; }
+    template <class T> T *as() { return reinterpret_cast<T *>(p); }
+};
+
+static int need_gpu()
+{
+    if (xq_device_count() <= 0) return fail(XQ_E_NOGPU, "no HIP device visible (the HIP path has no CPU fallback)");
+    return 0;
+}
+
+extern "C" int xq_rules_legal_moves(int n, const int8_t *boards, const int32_t *player, const int32_t *rk,
+                                    const int32_t *bk, uint16_t *moves, int32_t *counts)
+{
+    if (n <= 0 || !boards || !player || !rk || !bk || !moves || !counts) return fail(XQ_E_INVALID, "bad argument");
+    if (int rc = need_gpu()) return rc;
+    DevBuf dB, dP, dR, dK, dM, dC;
+    if (dB.alloc((size_t)n * 90) || dP.alloc((size_t)n * 4) || dR.alloc((size_t)n * 4) || dK.alloc((size_t)n * 4) ||
+        dM.alloc((size_t)n * MAXM * 2) || dC.alloc((size_t)n * 4))
+        return fail(XQ_E_HIP, "hipMalloc failed");
+    HIPCHK(hipMemcpy(dB.p, boards, (size_t)n * 90, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dP.p, player, (size_t)n * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dR.p, rk, (size_t)n * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dK.p, bk, (size_t)n * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemset(dM.p, 0, (size_t)n * MAXM * 2));
+    hipLaunchKernelGGL(k_rules_legal, dim3(n), dim3(64), 0, 0, n, dB.as<int8_t>(), dP.as<int32_t>(), dR.as<int32_t>(),
+                       dK.as<int32_t>(), dM.as<uint16_t>(), dC.as<int32_t>());
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpy(moves, dM.p, (size_t)n * MAXM * 2, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(counts, dC.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int xq_rules_query(int n, const int8_t *boards, const int32_t *player, const int32_t *rk, const int32_t *bk,
+                              int32_t *chk_red, int32_t *chk_black, int32_t *facing)
+{
+    if (n <= 0 || !boards || !player || !rk || !bk || !chk_red || !chk_black || !facing)
+        return fail(XQ_E_INVALID, "bad argument");
+    if (int rc = need_gpu()) return rc;
+    DevBuf dB, dP, dR, dK, d1, d2, d3;
+    if (dB.alloc((size_t)n * 90) || dP.alloc((size_t)n * 4) || dR.alloc((size_t)n * 4) || dK.alloc((size_t)n * 4) ||
+        d1.alloc((size_t)n * 4) || d2.alloc((size_t)n * 4) || d3.alloc((size_t)n * 4))
+        return fail(XQ_E_HIP, "hipMalloc failed");
+    HIPCHK(hipMemcpy(dB.p, boards, (size_t)n * 90, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dP.p, player, (size_t)n * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dR.p, rk, (size_t)n * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dK.p, bk, (size_t)n * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_rules_query, dim3(n), dim3(64), 0, 0, n, dB.as<int8_t>(), dP.as<int32_t>(), dR.as<int32_t>(),
+                       dK.as<int32_t>(), d1.as<int32_t>(), d2.as<int32_t>(), d3.as<int32_t>());
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpy(chk_red, d1.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(chk_black, d2.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(facing, d3.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int xq_rules_make_move(int n, int8_t *boards, int32_t *state, const int32_t *move,
+                                  const uint64_t *pos_hist, const int32_t *n_hist, const uint8_t *chk_hist,
+                                  const int32_t *n_chk, int stride, double *reward, int32_t *done,
+                                  int32_t *is_check, uint64_t *key_out, uint16_t *next_moves, int32_t *next_count)
+{
+    if (n <= 0 || !boards || !state || !move || !n_hist || !n_chk || !reward || !done || !is_check || !key_out ||
+        !next_moves || !next_count || stride < 0)
+        return fail(XQ_E_INVALID, "bad argument");
+    for (int i = 0; i < n; i++)
+        if (n_hist[i] < 0 || n_hist[i] > stride || n_chk[i] < 0 || n_chk[i] > stride)
+            return fail(XQ_E_INVALID, "history length exceeds hist_stride");
+    if (stride > 0 && (!pos_hist || !chk_hist)) return fail(XQ_E_INVALID, "history pointers missing");
+    if (int rc = need_gpu()) return rc;
+    const size_t hs = (size_t)n * (stride ? stride : 1);
+    DevBuf dB, dS, dM, dPH, dNH, dCH, dNC, dRw, dDn, dIc, dKy, dNm, dNn;
+    if (dB.alloc((size_t)n * 90) || dS.alloc((size_t)n * XQ_STATE_WORDS * 4) || dM.alloc((size_t)n * 4) ||
+        dPH.alloc(hs * 8) || dNH.alloc((size_t)n * 4) || dCH.alloc(hs) || dNC.alloc((size_t)n * 4) ||
+        dRw.alloc((size_t)n * 8) || dDn.alloc((size_t)n * 4) || dIc.alloc((size_t)n * 4) || dKy.alloc((size_t)n * 8) ||
+        dNm.alloc((size_t)n * MAXM * 2) || dNn.alloc((size_t)n * 4))
+        return fail(XQ_E_HIP, "hipMalloc failed");
+    HIPCHK(hipMemcpy(dB.p, boards, (size_t)n * 90, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dS.p, state, (size_t)n * XQ_STATE_WORDS * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dM.p, move, (size_t)n * 4, hipMemcpyHostToDevice));
+    if (stride > 0) {
+        HIPCHK(hipMemcpy(dPH.p, pos_hist, hs * 8, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(dCH.p, chk_hist, hs, hipMemcpyHostToDevice));
+    }
+    HIPCHK(hipMemcpy(dNH.p, n_hist, (size_t)n * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dNC.p, n_chk, (size_t)n * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemset(dNm.p, 0, (size_t)n * MAXM * 2));
+    hipLaunchKernelGGL(k_rules_make_move, dim3(n), dim3(64), 0, 0, n, dB.as<int8_t>(), dS.as<int32_t>(), dM.as<int32_t>(),
+                       dPH.as<uint64_t>(), dNH.as<int32_t>(), dCH.as<uint8_t>(), dNC.as<int32_t>(), stride,
+                       dRw.as<double>(), dDn.as<int32_t>(), dIc.as<int32_t>(), dKy.as<uint64_t>(), dNm.as<uint16_t>(),
+                       dNn.as<int32_t>());
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpy(boards, dB.p, (size_t)n * 90, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(state, dS.p, (size_t)n * XQ_STATE_WORDS * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(reward, dRw.p, (size_t)n * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(done, dDn.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(is_check, dIc.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(key_out, dKy.p, (size_t)n * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(next_moves, dNm.p, (size_t)n * MAXM * 2, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(next_count, dNn.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// ---- engine ------------------------------------------------------------------------------
+struct xq_engine {
+    xq_config cfg;
+    Eng E;
+    hipStream_t stream = nullptr;
+    std::vector<void *> allocs;
+    double *pow_table_dev = nullptr;
+    int *active_dev = nullptr;
+    int8_t *stage_boards = nullptr;      // [G][90] staging for set_roots / read_leaves
+    int32_t *stage_state = nullptr;      // [G][XQ_STATE_WORDS]
+    // profiling
+    bool prof = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_search, ev_play;
+    size_t ev_search_used = 0, ev_play_used = 0;
+    double search_ms = 0, play_ms = 0;
+    int64_t search_n = 0, play_n = 0;
+};
+
+template <class T> static int dalloc(xq_engine *e, T *&p, size_t count)
+{
+    void *q = nullptr;
+    if (hipMalloc(&q, count * sizeof(T) + 64) != hipSuccess) return -1;
+    if (hipMemset(q, 0, count * sizeof(T) + 64) != hipSuccess) return -1;
+    e->allocs.push_back(q);
+    p = reinterpret_cast<T *>(q);
+    return 0;
+}
+
+extern "C" int xq_engine_create(const xq_config *cfg, xq_engine **out)
+{
+    if (!cfg || !out) return fail(XQ_E_INVALID, "null argument");
+    if (cfg->n_games <= 0 || cfg->sims <= 0 || cfg->leaf_batch <= 0 || cfg->leaf_batch > 255 || cfg->max_moves <= 0)
+        return fail(XQ_E_INVALID, "n_games, sims, leaf_batch, max_moves must be positive (leaf_batch <= 255)");
+    if (int rc = need_gpu()) return rc;
+    HIPCHK(hipSetDevice(cfg->device));
+    if (!xq_device_ok(cfg->device)) return fail(XQ_E_NOGPU, "device is not gfx950: this library carries gfx950 code only");
+    if (int rc = ensure_crc_table(cfg->device)) return rc;
+    const int nrounds = (cfg->sims + cfg->leaf_batch - 1) / cfg->leaf_batch;
+    if (nrounds > 64) return fail(XQ_E_INVALID, "sims / leaf_batch too large (at most 64 rounds per move: one lane per path level)");
+    const long ncap_l = 1 + (long)nrounds * MAXM;
+    if (ncap_l > 65535) return fail(XQ_E_INVALID, "node arena exceeds 16-bit indices");
+    xq_engine *e = new xq_engine();
+    e->cfg = *cfg;
+    Eng &E = e->E;
+    memset(&E, 0, sizeof E);
+    E.G = cfg->n_games; E.ncap = (int)((ncap_l + 63) / 64 * 64); E.sims = cfg->sims; E.leaf_batch = cfg->leaf_batch;
+    E.nrounds = nrounds; E.max_moves = cfg->max_moves; E.opponent_mode = cfg->opponent_mode;
+    E.want_check = nrounds >= 12 ? 1 : 0;       // check_history only matters once 12 plies fit a path
+    E.temperature = cfg->temperature;
+    const size_t G = (size_t)E.G, NC = (size_t)E.ncap;
+    int bad = 0;
+    bad |= dalloc(e, E.board, G * 12); bad |= dalloc(e, E.gs, G); bad |= dalloc(e, E.pos_hist, G * PATH_CAP);
+    bad |= dalloc(e, E.chk_hist, G * PATH_CAP); bad |= dalloc(e, E.root_moves, G * MAXM);
+    bad |= dalloc(e, E.uniforms, G * XQ_MAX_PLIES);
+    bad |= dalloc(e, E.nN, G * NC); bad |= dalloc(e, E.nW, G * NC); bad |= dalloc(e, E.nP, G * NC);
+    bad |= dalloc(e, E.nMove, G * NC); bad |= dalloc(e, E.nFirst, G * NC); bad |= dalloc(e, E.nNc, G * NC);
+    bad |= dalloc(e, E.nFlags, G * NC); bad |= dalloc(e, E.n_nodes, G);
+    bad |= dalloc(e, E.leaf_node, G); bad |= dalloc(e, E.leaf_mult, G); bad |= dalloc(e, E.leaf_n, G);
+    bad |= dalloc(e, E.leaf_depth, G); bad |= dalloc(e, E.leaf_moves, G * MAXM); bad |= dalloc(e, E.leaf_path, G * PATH_CAP);
+    bad |= dalloc(e, E.leaf_board, G * 12); bad |= dalloc(e, E.leaf_side, G);
+    bad |= dalloc(e, E.priors, G * MAXM); bad |= dalloc(e, E.values, G);
+    bad |= dalloc(e, E.s_board, G * XQ_MAX_PLIES * 12); bad |= dalloc(e, E.s_player, G * XQ_MAX_PLIES);
+    bad |= dalloc(e, E.s_n, G * XQ_MAX_PLIES); bad |= dalloc(e, E.s_moves, G * XQ_MAX_PLIES * MAXM);
+    bad |= dalloc(e, E.s_counts, G * XQ_MAX_PLIES * MAXM); bad |= dalloc(e, E.s_z, G * XQ_MAX_PLIES);
+    bad |= dalloc(e, E.step_reward, G * XQ_MAX_PLIES); bad |= dalloc(e, E.t_move, G * XQ_MAX_PLIES);
+    bad |= dalloc(e, e->active_dev, 1); bad |= dalloc(e, e->stage_boards, G * 90);
+    bad |= dalloc(e, e->stage_state, G * XQ_STATE_WORDS);
+    if (bad) {
+        xq_engine_destroy(e);
+        return fail(XQ_E_HIP, "hipMalloc failed while sizing the engine");
+    }
+    *out = e;
+    return 0;
+}
+
+extern "C" void xq_engine_destroy(xq_engine *e)
+{
+    if (!e) return;
+    (void)hipSetDevice(e->cfg.device);
+    (void)hipDeviceSynchronize();
+    for (void *p : e->allocs) (void)hipFree(p);
+    for (auto &pr : e->ev_search) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+    for (auto &pr : e->ev_play) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+    delete e;
+}
+
+extern "C" int xq_engine_set_stream(xq_engine *e, void *s)
+{
+    if (!e) return fail(XQ_E_INVALID, "null engine");
+    e->stream = reinterpret_cast<hipStream_t>(s);
+    return 0;
+}
+
+extern "C" int xq_engine_set_pow_table(xq_engine *e, const double *t, int n)
+{
+    if (!e) return fail(XQ_E_INVALID, "null engine");
+    if (!t || n <= 0) { e->E.pow_table = nullptr; e->E.pow_n = 0; return 0; }
+    double *p = nullptr;
+    if (dalloc(e, p, (size_t)n)) return fail(XQ_E_HIP, "hipMalloc failed");
+    HIPCHK(hipMemcpyAsync(p, t, (size_t)n * 8, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    e->E.pow_table = p; e->E.pow_n = n;
+    return 0;
+}
+
+// np.random.seed(int) + 70 x random_sample() per game (MT19937, 53-bit doubles)
+static void mt_uniforms(uint32_t seed, double *out, int count)
+{
+    static thread_local uint32_t mt[624];
+    mt[0] = seed;
+    for (int i = 1; i < 624; i++) mt[i] = 1812433253u * (mt[i - 1] ^ (mt[i - 1] >> 30)) + (uint32_t)i;
+    int idx = 624;
+    auto next = [&]() -> uint32_t {
+        if (idx >= 624) {
+            int i;
+            for (i = 0; i < 624 - 397; i++) {
+                uint32_t y = (mt[i] & 0x80000000u) | (mt[i + 1] & 0x7fffffffu);
+                mt[i] = mt[i + 397] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+            }
+            for (; i < 623; i++) {
+                uint32_t y = (mt[i] & 0x80000000u) | (mt[i + 1] & 0x7fffffffu);
+                mt[i] = mt[i + (397 - 624)] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+            }
+            uint32_t y = (mt[623] & 0x80000000u) | (mt[0] & 0x7fffffffu);
+            mt[623] = mt[396] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+            idx = 0;
+        }
+        uint32_t y = mt[idx++];
+        y ^= (y >> 11); y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= (y >> 18);
+        return y;
+    };
+    for (int k = 0; k < count; k++) {
+        uint32_t a = next() >> 5, b = next() >> 6;
+        out[k] = (a * 67108864.0 + b) / 9007199254740992.0;
+    }
+}
+
+extern "C" int xq_engine_new_games(xq_engine *e, const uint32_t *seeds)
+{
+    if (!e || !seeds) return fail(XQ_E_INVALID, "null argument");
+    HIPCHK(hipSetDevice(e->cfg.device));
+    const size_t G = (size_t)e->E.G;
+    std::vector<double> u(G * XQ_MAX_PLIES);
+    for (size_t g = 0; g < G; g++) mt_uniforms(seeds[g], u.data() + g * XQ_MAX_PLIES, XQ_MAX_PLIES);
+    HIPCHK(hipMemcpyAsync(e->E.uniforms, u.data(), u.size() * 8, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));          // u is a local: copy must finish
+    hipLaunchKernelGGL(k_new_games, dim3(e->E.G), dim3(64), 0, e->stream, e->E);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int xq_engine_set_uniforms(xq_engine *e, const double *u)
+{
+    if (!e || !u) return fail(XQ_E_INVALID, "null argument");
+    HIPCHK(hipSetDevice(e->cfg.device));
+    HIPCHK(hipMemcpyAsync(e->E.uniforms, u, (size_t)e->E.G * XQ_MAX_PLIES * 8, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return 0;
+}
+
+extern "C" int xq_engine_set_roots(xq_engine *e, const int8_t *boards, const int32_t *state)
+{
+    if (!e || !boards || !state) return fail(XQ_E_INVALID, "null argument");
+    HIPCHK(hipSetDevice(e->cfg.device));
+    const size_t G = (size_t)e->E.G;
+    HIPCHK(hipMemcpyAsync(e->stage_boards, boards, G * 90, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(e->stage_state, state, G * XQ_STATE_WORDS * 4, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    hipLaunchKernelGGL(k_set_roots, dim3(e->E.G), dim3(64), 0, e->stream, e->E, e->stage_boards, e->stage_state);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+static int planes_ok(int fmt) { return fmt >= XQ_PLANES_NONE && fmt <= XQ_PLANES_NHWC16_BF16; }
+
+static std::pair<hipEvent_t, hipEvent_t> *next_events(std::vector<std::pair<hipEvent_t, hipEvent_t>> &pool, size_t &used)
+{
+    if (used == pool.size()) {
+        hipEvent_t a, b;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return nullptr;
+        pool.emplace_back(a, b);
+    }
+    return &pool[used++];
+}
+
+static int drain_events(xq_engine *e)
+{
+    HIPCHK(hipStreamSynchronize(e->stream));
+    for (size_t i = 0; i < e->ev_search_used; i++) {
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, e->ev_search[i].first, e->ev_search[i].second));
+        e->search_ms += ms; e->search_n++;
+    }
+    for (size_t i = 0; i < e->ev_play_used; i++) {
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, e->ev_play[i].first, e->ev_play[i].second));
+        e->play_ms += ms; e->play_n++;
+    }
+    e->ev_search_used = e->ev_play_used = 0;
+    return 0;
+}
+
+extern "C" int xq_engine_search_round(xq_engine *e, int round, int eval_kind, const void *ev_a, const void *ev_v,
+                                      void *planes)
+{
+    if (!e) return fail(XQ_E_INVALID, "null engine");
+    if (round < 0 || round >= e->E.nrounds) return fail(XQ_E_INVALID, "round out of range");
+    if (eval_kind < XQ_EVAL_PRIORS || eval_kind > XQ_EVAL_LOGITS_BF16) return fail(XQ_E_INVALID, "bad eval_kind");
+    if (round > 0 && (!ev_a || !ev_v)) return fail(XQ_E_INVALID, "evaluator output missing");
+    if (!planes_ok(e->cfg.planes_format)) return fail(XQ_E_INVALID, "bad planes_format");
+    HIPCHK(hipSetDevice(e->cfg.device));
+    const int start = round * e->E.leaf_batch;
+    const int batch = (start + e->E.leaf_batch <= e->E.sims) ? e->E.leaf_batch : e->E.sims - start;
+    std::pair<hipEvent_t, hipEvent_t> *ev = nullptr;
+    if (e->prof) {
+        if (e->ev_search_used >= 4096) { if (int rc = drain_events(e)) return rc; }
+        ev = next_events(e->ev_search, e->ev_search_used);
+        if (ev) HIPCHK(hipEventRecord(ev->first, e->stream));
+    }
+    hipLaunchKernelGGL(k_search_round, dim3(e->E.G), dim3(64), 0, e->stream, e->E, round, batch, eval_kind, ev_a, ev_v,
+                       planes, planes ? e->cfg.planes_format : XQ_PLANES_NONE);
+    HIPCHK(hipGetLastError());
+    if (ev) HIPCHK(hipEventRecord(ev->second, e->stream));
+    return 0;
+}
+
+extern "C" int xq_engine_eval_hashnet(xq_engine *e, int salt)
+{
+    if (!e) return fail(XQ_E_INVALID, "null engine");
+    HIPCHK(hipSetDevice(e->cfg.device));
+    hipLaunchKernelGGL(k_hashnet, dim3(e->E.G), dim3(64), 0, e->stream, e->E, salt);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int xq_engine_end_search(xq_engine *e, int eval_kind, const void *ev_a, const void *ev_v)
+{
+    if (!e || !ev_a || !ev_v) return fail(XQ_E_INVALID, "null argument");
+    if (eval_kind < XQ_EVAL_PRIORS || eval_kind > XQ_EVAL_LOGITS_BF16) return fail(XQ_E_INVALID, "bad eval_kind");
+    HIPCHK(hipSetDevice(e->cfg.device));
+    hipLaunchKernelGGL(k_end_search, dim3(e->E.G), dim3(64), 0, e->stream, e->E, eval_kind, ev_a, ev_v);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int xq_engine_play_move(xq_engine *e)
+{
+    if (!e) return fail(XQ_E_INVALID, "null engine");
+    HIPCHK(hipSetDevice(e->cfg.device));
+    std::pair<hipEvent_t, hipEvent_t> *ev = nullptr;
+    if (e->prof) {
+        ev = next_events(e->ev_play, e->ev_play_used);
+        if (ev) HIPCHK(hipEventRecord(ev->first, e->stream));
+    }
+    hipLaunchKernelGGL(k_play_move, dim3(e->E.G), dim3(64), 0, e->stream, e->E);
+    HIPCHK(hipGetLastError());
+    if (ev) HIPCHK(hipEventRecord(ev->second, e->stream));
+    return 0;
+}
+
+extern "C" int xq_engine_finalize(xq_engine *e)
+{
+    if (!e) return fail(XQ_E_INVALID, "null engine");
+    HIPCHK(hipSetDevice(e->cfg.device));
+    hipLaunchKernelGGL(k_finalize, dim3(e->E.G), dim3(64), 0, e->stream, e->E);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int xq_engine_active_games(xq_engine *e, int32_t *n)
+{
+    if (!e || !n) return fail(XQ_E_INVALID, "null argument");
+    HIPCHK(hipSetDevice(e->cfg.device));
+    HIPCHK(hipMemsetAsync(e->active_dev, 0, 4, e->stream));
+    hipLaunchKernelGGL(k_count_active, dim3((e->E.G + 255) / 256), dim3(256), 0, e->stream, e->E.gs, e->E.G, e->active_dev);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(n, e->active_dev, 4, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return 0;
+}
+
+extern "C" void *xq_engine_priors_ptr(xq_engine *e) { return e ? e->E.priors : nullptr; }
+extern "C" void *xq_engine_values_ptr(xq_engine *e) { return e ? e->E.values : nullptr; }
+extern "C" int xq_engine_rounds_per_move(xq_engine *e) { return e ? e->E.nrounds : 0; }
+
+template <class T> static int d2h(xq_engine *e, T *dst, const T *src, size_t count)
+{
+    if (!dst) return 0;
+    HIPCHK(hipMemcpyAsync(dst, src, count * sizeof(T), hipMemcpyDeviceToHost, e->stream));
+    return 0;
+}
+
+static void unpack_board_host(const uint32_t *w, int8_t *out)
+{
+    for (int s = 0; s < 90; s++) {
+        uint32_t code = (w[s / 8] >> (4 * (s % 8))) & 15u;
+        out[s] = (int8_t)(code <= 7 ? (int)code : 7 - (int)code);
+    }
+}
+
+extern "C" int xq_engine_read_leaves(xq_engine *e, int8_t *boards, int32_t *player, uint16_t *moves, int32_t *n_moves,
+                                     int32_t *mult)
+{
+    if (!e) return fail(XQ_E_INVALID, "null engine");
+    HIPCHK(hipSetDevice(e->cfg.device));
+    const size_t G = (size_t)e->E.G;
+    std::vector<uint32_t> pb(G * 12);
+    std::vector<int8_t> side(G);
+    std::vector<uint8_t> n(G), m(G);
+    std::vector<uint16_t> node(G);
+    if (int rc = d2h(e, pb.data(), e->E.leaf_board, G * 12)) return rc;
+    if (int rc = d2h(e, side.data(), e->E.leaf_side, G)) return rc;
+    if (int rc = d2h(e, n.data(), e->E.leaf_n, G)) return rc;
+    if (int rc = d2h(e, m.data(), e->E.leaf_mult, G)) return rc;
+    if (int rc = d2h(e, node.data(), e->E.leaf_node, G)) return rc;
+    if (int rc = d2h(e, moves, e->E.leaf_moves, G * MAXM)) return rc;
+    HIPCHK(hipStreamSynchronize(e->stream));
+    for (size_t g = 0; g < G; g++) {
+        const bool pending = node[g] != LEAF_NONE;
+        if (boards) unpack_board_host(pb.data() + g * 12, boards + g * 90);
+        if (player) player[g] = side[g];
+        if (n_moves) n_moves[g] = pending ? n[g] : 0;
+        if (mult) mult[g] = pending ? m[g] : 0;
+    }
+    return 0;
+}
+
+extern "C" int xq_engine_write_priors(xq_engine *e, const float *priors, const double *values)
+{
+    if (!e || !priors || !values) return fail(XQ_E_INVALID, "null argument");
+    HIPCHK(hipSetDevice(e->cfg.device));
+    const size_t G = (size_t)e->E.G;
+    HIPCHK(hipMemcpyAsync(e->E.priors, priors, G * MAXM * 4, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(e->E.values, values, G * 8, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return 0;
+}
+
+extern "C" int xq_engine_read_root_visits(xq_engine *e, uint16_t *moves, int32_t *visits, int32_t *n_child)
+{
+    if (!e || !moves || !visits || !n_child) return fail(XQ_E_INVALID, "null argument");
+    HIPCHK(hipSetDevice(e->cfg.device));
+    const size_t G = (size_t)e->E.G, NC = (size_t)e->E.ncap;
+    // root children occupy nodes [first, first+nc) with first == 1 when expanded
+    std::vector<uint8_t> nc(G);
+    std::vector<uint16_t> first(G);
+    HIPCHK(hipMemcpy2DAsync(nc.data(), 1, e->E.nNc, NC, 1, G, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpy2DAsync(first.data(), 2, e->E.nFirst, NC * 2, 2, G, hipMemcpyDeviceToHost, e->stream));
+    std::vector<uint32_t> N(G * (MAXM + 1));
+    std::vector<uint16_t> mv(G * (MAXM + 1));
+    HIPCHK(hipMemcpy2DAsync(N.data(), (MAXM + 1) * 4, e->E.nN, NC * 4, (MAXM + 1) * 4, G, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpy2DAsync(mv.data(), (MAXM + 1) * 2, e->E.nMove, NC * 2, (MAXM + 1) * 2, G, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    for (size_t g = 0; g < G; g++) {
+        n_child[g] = nc[g];
+        for (int j = 0; j < MAXM; j++) {
+            const bool ok = j < nc[g] && first[g] == 1;
+            moves[g * MAXM + j] = ok ? mv[g * (MAXM + 1) + 1 + j] : 0;
+            visits[g * MAXM + j] = ok ? (int32_t)N[g * (MAXM + 1) + 1 + j] : 0;
+        }
+    }
+    return 0;
+}
+
+extern "C" int xq_engine_read_games(xq_engine *e, int32_t *winner, int32_t *reason, int32_t *reason_side,
+                                    int32_t *reason_count, int32_t *n_plies, int32_t *n_samples, int32_t *error)
+{
+    if (!e) return fail(XQ_E_INVALID, "null engine");
+    HIPCHK(hipSetDevice(e->cfg.device));
+    const size_t G = (size_t)e->E.G;
+    std::vector<GameS> gs(G);
+    HIPCHK(hipMemcpyAsync(gs.data(), e->E.gs, G * sizeof(GameS), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    for (size_t g = 0; g < G; g++) {
+        if (winner) winner[g] = gs[g].winner == WINNER_NONE ? 0 : gs[g].winner;       // self_play.py:259
+        if (reason) reason[g] = gs[g].reason;
+        if (reason_side) reason_side[g] = gs[g].reason_side;
+        if (reason_count) reason_count[g] = gs[g].reason_count;
+        if (n_plies) n_plies[g] = gs[g].n_plies;
+        if (n_samples) n_samples[g] = gs[g].n_samples;
+        if (error) error[g] = gs[g].error;
+    }
+    return 0;
+}
+
+extern "C" int xq_engine_read_samples(xq_engine *e, int8_t *boards, int8_t *player, uint8_t *n_moves, uint16_t *moves,
+                                      uint16_t *counts, double *z, uint16_t *chosen, double *step_reward)
+{
+    if (!e) return fail(XQ_E_INVALID, "null engine");
+    HIPCHK(hipSetDevice(e->cfg.device));
+    const size_t GP = (size_t)e->E.G * XQ_MAX_PLIES;
+    std::vector<uint32_t> pb;
+    if (boards) {
+        pb.resize(GP * 12);
+        if (int rc = d2h(e, pb.data(), e->E.s_board, GP * 12)) return rc;
+    }
+    if (int rc = d2h(e, player, e->E.s_player, GP)) return rc;
+    if (int rc = d2h(e, n_moves, e->E.s_n, GP)) return rc;
+    if (int rc = d2h(e, moves, e->E.s_moves, GP * MAXM)) return rc;
+    if (int rc = d2h(e, counts, e->E.s_counts, GP * MAXM)) return rc;
+    if (int rc = d2h(e, z, e->E.s_z, GP)) return rc;
+    if (int rc = d2h(e, chosen, e->E.t_move, GP)) return rc;
+    if (int rc = d2h(e, step_reward, e->E.step_reward, GP)) return rc;
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if (boards)
+        for (size_t i = 0; i < GP; i++) unpack_board_host(pb.data() + i * 12, boards + i * 90);
+    return 0;
+}
+
+extern "C" int xq_engine_pack_samples(xq_engine *e, void *records)
+{
+    if (!e || !records) return fail(XQ_E_INVALID, "null argument");
+    HIPCHK(hipSetDevice(e->cfg.device));
+    hipLaunchKernelGGL(k_pack_samples, dim3(e->E.G), dim3(64), 0, e->stream, e->E,
+                       reinterpret_cast<xq_sample_record *>(records));
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int xq_engine_profile(xq_engine *e, int enable)
+{
+    if (!e) return fail(XQ_E_INVALID, "null engine");
+    if (int rc = drain_events(e)) return rc;
+    e->prof = enable != 0;
+    if (enable) { e->search_ms = e->play_ms = 0; e->search_n = e->play_n = 0; }
+    return 0;
+}
+
+extern "C" int xq_engine_profile_read(xq_engine *e, double *search_ms, int64_t *search_n, double *play_ms, int64_t *play_n)
+{
+    if (!e) return fail(XQ_E_INVALID, "null engine");
+    if (int rc = drain_events(e)) return rc;
+    if (search_ms) *search_ms = e->search_ms;
+    if (search_n) *search_n = e->search_n;
+    if (play_ms) *play_ms = e->play_ms;
+    if (play_n) *play_n = e->play_n;
+    return 0;
+}

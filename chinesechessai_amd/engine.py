@@ -1,0 +1,296 @@
+"""Host driver of the batched self-play engine (one process per GPU, G games in lock-step).
+
+Per ply:  R = ceil(sims / 8) rounds of { tree kernel (select / rules / terminal backups, leaf
+planes) -> evaluator }  then  { consume, pi, np.random.choice, make_move }  — the loop of
+MCTS.search (self_play.py:103-148) and self_play_game (self_play.py:203-256) for all games at
+once.  Everything stays on the device and on one HIP stream; Python only enqueues.
+
+Evaluators:
+  HashNetEvaluator   exact dyadic priors/values computed by a HIP kernel (parity tests)
+  TorchNetEvaluator  InferenceNet under PyTorch-ROCm (the production leaf evaluator)
+  CallbackEvaluator  any object with the reference's predict_batch (duck-typed, self_play.py:143)
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .chess_env import decode_move, format_end_reason
+
+
+class HashNetEvaluator:
+    """SURVEY.md Appendix B evaluator, on the GPU."""
+    planes_format = _lib.PLANES_NONE
+
+    def __init__(self, salt=0):
+        self.salt = salt
+
+    def bind(self, engine):
+        pass
+
+    def planes_ptr(self):
+        return None
+
+    def evaluate(self, engine):
+        _lib.check(engine.L.xq_engine_eval_hashnet(engine.h, self.salt))
+        return _lib.EVAL_PRIORS, engine.priors_ptr, engine.values_ptr
+
+
+class CallbackEvaluator:
+    """Reference-style network object: predict_batch([(board, player, legal_moves)]) ->
+    [(dict move->prior, value)] (neural_network.py:96-126).  Rows are passed with the same
+    multiplicity the reference passes them (self_play.py:139-143)."""
+    planes_format = _lib.PLANES_NONE
+
+    def __init__(self, network):
+        self.network = network
+
+    def bind(self, engine):
+        G = engine.n_games
+        self.boards = np.zeros((G, 90), np.int8)
+        self.player = np.zeros(G, np.int32)
+        self.moves = np.zeros((G, _lib.MAX_MOVES), np.uint16)
+        self.n_moves = np.zeros(G, np.int32)
+        self.mult = np.zeros(G, np.int32)
+        self.priors = np.zeros((G, _lib.MAX_MOVES), np.float32)
+        self.values = np.zeros(G, np.float64)
+
+    def planes_ptr(self):
+        return None
+
+    def evaluate(self, engine):
+        L = engine.L
+        _lib.check(L.xq_engine_read_leaves(engine.h, _lib.ptr(self.boards), _lib.ptr(self.player), _lib.ptr(self.moves),
+                                            _lib.ptr(self.n_moves), _lib.ptr(self.mult)))
+        for g in range(engine.n_games):
+            m = int(self.mult[g])
+            if m == 0:
+                continue
+            legal = [decode_move(x) for x in self.moves[g, :self.n_moves[g]]]
+            row = (self.boards[g].reshape(10, 9).copy(), int(self.player[g]), legal)
+            res = self.network.predict_batch([row] * m)
+            probs, value = res[0]
+            self.priors[g, :len(legal)] = [np.float32(probs[mv]) for mv in legal]
+            self.values[g] = float(value)
+        _lib.check(L.xq_engine_write_priors(engine.h, _lib.ptr(self.priors), _lib.ptr(self.values)))
+        return _lib.EVAL_PRIORS, engine.priors_ptr, engine.values_ptr
+
+
+class TorchNetEvaluator:
+    """InferenceNet under PyTorch-ROCm; the search kernel writes its input planes in place."""
+
+    def __init__(self, net, dtype=None, channels_last=True, chunk=None):
+        import torch
+        from .neural_network import InferenceNet
+        self.torch = torch
+        dtype = dtype or torch.bfloat16
+        self.dtype = dtype
+        if dtype == torch.bfloat16:
+            self.planes_format = _lib.PLANES_NHWC16_BF16 if channels_last else _lib.PLANES_NCHW_BF16
+        elif dtype == torch.float32:
+            self.planes_format = _lib.PLANES_NCHW_F32
+            channels_last = False
+        else:
+            raise ValueError("dtype must be bfloat16 or float32")
+        self.channels_last = channels_last
+        self.inet = net if isinstance(net, InferenceNet) else InferenceNet(
+            net, dtype=dtype, c_in=16 if channels_last else 15, device="cuda")
+        self.chunk = chunk
+        self.kind = _lib.EVAL_LOGITS_BF16 if dtype == torch.bfloat16 else _lib.EVAL_LOGITS_F32
+
+    def bind(self, engine):
+        torch = self.torch
+        G = engine.n_games
+        if self.channels_last:
+            self.storage = torch.zeros((G, 10, 9, 16), dtype=self.dtype, device="cuda")
+            self.x = self.storage.permute(0, 3, 1, 2)            # logical NCHW, channels-last strides
+        else:
+            self.storage = torch.zeros((G, 15, 10, 9), dtype=self.dtype, device="cuda")
+            self.x = self.storage
+        self.logits = torch.empty((G, _lib.POLICY_SIZE), dtype=self.dtype, device="cuda")
+        self.values = torch.empty((G,), dtype=self.dtype, device="cuda")
+
+    def planes_ptr(self):
+        return self.storage.data_ptr()
+
+    def evaluate(self, engine):
+        G = engine.n_games
+        step = self.chunk or G
+        for s in range(0, G, step):
+            lg, v = self.inet(self.x[s:s + step])
+            self.logits[s:s + step] = lg
+            self.values[s:s + step] = v
+        return self.kind, self.logits.data_ptr(), self.values.data_ptr()
+
+
+class GameBatch:
+    """Results of one batch of games, in the reference's vocabulary."""
+
+    def __init__(self, n_games, temperature):
+        self.n_games = n_games
+        self.temperature = temperature
+
+    def game_data(self, g):
+        """[(board int8[10,9], {move: np.float64 prob}, z float)] as self_play_game returns it
+        (self_play.py:234-239, 310)."""
+        out = []
+        for i in range(int(self.n_samples[g])):
+            n = int(self.s_n[g, i])
+            moves = [decode_move(m) for m in self.s_moves[g, i, :n]]
+            counts = self.s_counts[g, i, :n].astype(np.int64)
+            if self.temperature < 0.01:                       # self_play.py:224-227
+                probs = np.zeros(n)
+                probs[np.argmax(counts)] = 1
+            else:                                             # self_play.py:230-231
+                c = counts ** (1.0 / self.temperature)
+                probs = c / c.sum()
+            out.append((self.s_board[g, i].reshape(10, 9).copy(), {m: p for m, p in zip(moves, probs)},
+                        float(self.s_z[g, i])))
+        return out
+
+    def end_reason(self, g):
+        s = format_end_reason(int(self.reason[g]), int(self.reason_side[g]), int(self.reason_count[g]))
+        return s if s else "未知原因"                           # self_play.py:260
+
+    def results(self):
+        """[(game_data, winner, end_reason)] — the return value of parallel_self_play
+        (self_play.py:469); failed games (np.random.choice ValueError) are dropped like the
+        reference drops (None, None, None) results (self_play.py:415-416)."""
+        return [(self.game_data(g), int(self.winner[g]), self.end_reason(g))
+                for g in range(self.n_games) if self.error[g] == 0]
+
+
+class SelfPlayEngine:
+    def __init__(self, n_games, sims=50, temperature=1.0, max_moves=70, opponent_mode=False,
+                 planes_format=_lib.PLANES_NONE, device=0, leaf_batch=8, stream=None):
+        self.L = _lib.lib()
+        if self.L.xq_device_count() <= 0:
+            raise _lib.XqError("no HIP device visible: the engine has no CPU fallback")
+        self.n_games, self.sims, self.temperature, self.max_moves = n_games, sims, temperature, max_moves
+        self.opponent_mode = opponent_mode
+        cfg = _lib.Config(n_games, sims, leaf_batch, max_moves, float(temperature), 1 if opponent_mode else 0,
+                          planes_format, device, 0)
+        h = C.c_void_p()
+        _lib.check(self.L.xq_engine_create(C.byref(cfg), C.byref(h)))
+        self.h = h
+        self.rounds = self.L.xq_engine_rounds_per_move(h)
+        self.priors_ptr = self.L.xq_engine_priors_ptr(h)
+        self.values_ptr = self.L.xq_engine_values_ptr(h)
+        if stream is not None:
+            _lib.check(self.L.xq_engine_set_stream(h, C.c_void_p(stream)))
+        if temperature >= 0.01 and temperature != 1.0:
+            # counts ** (1/T) exactly as the host's numpy evaluates it (self_play.py:230)
+            tab = np.arange(sims + 1, dtype=np.int64) ** (1.0 / temperature)
+            tab = np.ascontiguousarray(tab, dtype=np.float64)
+            _lib.check(self.L.xq_engine_set_pow_table(h, _lib.ptr(tab), len(tab)))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.xq_engine_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- low-level steps ------------------------------------------------------------------
+    def new_games(self, seeds):
+        seeds = np.ascontiguousarray(seeds, dtype=np.uint32)
+        assert seeds.shape == (self.n_games,)
+        _lib.check(self.L.xq_engine_new_games(self.h, _lib.ptr(seeds)))
+
+    def set_uniforms(self, u):
+        u = np.ascontiguousarray(u, dtype=np.float64)
+        assert u.shape == (self.n_games, _lib.MAX_PLIES)
+        _lib.check(self.L.xq_engine_set_uniforms(self.h, _lib.ptr(u)))
+
+    def set_roots(self, boards, states):
+        boards = np.ascontiguousarray(boards, dtype=np.int8).reshape(self.n_games, 90)
+        states = np.ascontiguousarray(states, dtype=np.int32).reshape(self.n_games, _lib.STATE_WORDS)
+        _lib.check(self.L.xq_engine_set_roots(self.h, _lib.ptr(boards), _lib.ptr(states)))
+
+    def search(self, evaluator):
+        """One MCTS.search for every game (self_play.py:89-154); root visits are final after it."""
+        kind, a, v = _lib.EVAL_PRIORS, None, None
+        pp = evaluator.planes_ptr()
+        for r in range(self.rounds):
+            _lib.check(self.L.xq_engine_search_round(self.h, r, kind, a, v, pp))
+            kind, a, v = evaluator.evaluate(self)
+        _lib.check(self.L.xq_engine_end_search(self.h, kind, a, v))
+
+    def root_visits(self):
+        G = self.n_games
+        moves = np.zeros((G, _lib.MAX_MOVES), np.uint16)
+        visits = np.zeros((G, _lib.MAX_MOVES), np.int32)
+        n = np.zeros(G, np.int32)
+        _lib.check(self.L.xq_engine_read_root_visits(self.h, _lib.ptr(moves), _lib.ptr(visits), _lib.ptr(n)))
+        return moves, visits, n
+
+    def active_games(self):
+        n = np.zeros(1, np.int32)
+        _lib.check(self.L.xq_engine_active_games(self.h, _lib.ptr(n)))
+        return int(n[0])
+
+    # ---- whole games ------------------------------------------------------------------------
+    def play(self, evaluator, seeds, opponent_evaluator=None, uniforms=None, check_every=8, read=True):
+        """Play G games to the end (self_play_game for every game).  `seeds[g]` seeds game g's
+        MT19937 stream like np.random.seed; `uniforms` overrides the streams."""
+        evaluator.bind(self)
+        if opponent_evaluator is not None:
+            opponent_evaluator.bind(self)
+        self.new_games(seeds)
+        if uniforms is not None:
+            self.set_uniforms(uniforms)
+        for ply in range(min(self.max_moves, _lib.MAX_PLIES)):
+            ev = evaluator if (ply % 2 == 0 or opponent_evaluator is None) else opponent_evaluator   # self_play.py:211
+            self.search(ev)
+            _lib.check(self.L.xq_engine_play_move(self.h))
+            if check_every and ply % check_every == check_every - 1 and self.active_games() == 0:
+                break
+        _lib.check(self.L.xq_engine_finalize(self.h))
+        return self.read_results() if read else None
+
+    def read_results(self):
+        G, P, M = self.n_games, _lib.MAX_PLIES, _lib.MAX_MOVES
+        b = GameBatch(G, self.temperature)
+        for name in ("winner", "reason", "reason_side", "reason_count", "n_plies", "n_samples", "error"):
+            setattr(b, name, np.zeros(G, np.int32))
+        _lib.check(self.L.xq_engine_read_games(self.h, _lib.ptr(b.winner), _lib.ptr(b.reason), _lib.ptr(b.reason_side),
+                                               _lib.ptr(b.reason_count), _lib.ptr(b.n_plies), _lib.ptr(b.n_samples),
+                                               _lib.ptr(b.error)))
+        b.s_board = np.zeros((G, P, 90), np.int8)
+        b.s_player = np.zeros((G, P), np.int8)
+        b.s_n = np.zeros((G, P), np.uint8)
+        b.s_moves = np.zeros((G, P, M), np.uint16)
+        b.s_counts = np.zeros((G, P, M), np.uint16)
+        b.s_z = np.zeros((G, P), np.float64)
+        b.chosen = np.zeros((G, P), np.uint16)
+        b.step_reward = np.zeros((G, P), np.float64)
+        _lib.check(self.L.xq_engine_read_samples(self.h, _lib.ptr(b.s_board), _lib.ptr(b.s_player), _lib.ptr(b.s_n),
+                                                 _lib.ptr(b.s_moves), _lib.ptr(b.s_counts), _lib.ptr(b.s_z),
+                                                 _lib.ptr(b.chosen), _lib.ptr(b.step_reward)))
+        return b
+
+    def read_game_outcomes(self):
+        """Only the per-game scalars (cheap)."""
+        G = self.n_games
+        out = {k: np.zeros(G, np.int32) for k in ("winner", "reason", "reason_side", "reason_count", "n_plies",
+                                                  "n_samples", "error")}
+        _lib.check(self.L.xq_engine_read_games(self.h, *[_lib.ptr(out[k]) for k in (
+            "winner", "reason", "reason_side", "reason_count", "n_plies", "n_samples", "error")]))
+        return out
+
+    def pack_samples(self, records_ptr):
+        """Fixed-size device-resident sample records for the all-gather (distributed.py)."""
+        _lib.check(self.L.xq_engine_pack_samples(self.h, C.c_void_p(records_ptr)))
+
+    def profile(self, enable):
+        _lib.check(self.L.xq_engine_profile(self.h, 1 if enable else 0))
+
+    def profile_read(self):
+        sm, pm = C.c_double(), C.c_double()
+        sn, pn = C.c_int64(), C.c_int64()
+        _lib.check(self.L.xq_engine_profile_read(self.h, C.byref(sm), C.byref(sn), C.byref(pm), C.byref(pn)))
+        return dict(search_ms=sm.value, search_launches=sn.value, play_ms=pm.value, play_launches=pn.value)

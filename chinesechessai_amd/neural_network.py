@@ -1,0 +1,180 @@
+"""Policy/value network of the reference (neural_network.py:12-187) under PyTorch-ROCm.
+
+`ChessNet` keeps the reference's parameter names so that a reference `state_dict` loads unchanged
+(keys conv1, bn1, res_blocks.{i}.{conv1,bn1,conv2,bn2}, policy_conv, policy_bn, policy_fc,
+value_conv, value_bn, value_fc1, value_fc2); `num_blocks` generalises the hard-coded 4
+(neural_network.py:29-31) for the 6- and 20-block BASELINE configs.
+
+`InferenceNet` is the leaf evaluator the engine drives: eval-mode BatchNorm folded into the
+convolutions, bf16 (or fp32) weights, channels-last activations, input planes written directly by
+the search kernel.  The network is the only MFMA user on the path; everything else is integer work.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .config import BOARD_SIZE, BOARD_WIDTH
+
+
+class ResidualBlock(nn.Module):
+    """neural_network.py:172-187"""
+
+    def __init__(self, num_channels):
+        super().__init__()
+        self.conv1 = nn.Conv2d(num_channels, num_channels, kernel_size=3, padding=1)
+        self.bn1 = nn.BatchNorm2d(num_channels)
+        self.conv2 = nn.Conv2d(num_channels, num_channels, kernel_size=3, padding=1)
+        self.bn2 = nn.BatchNorm2d(num_channels)
+
+    def forward(self, x):
+        residual = x
+        out = F.relu(self.bn1(self.conv1(x)))
+        out = self.bn2(self.conv2(out))
+        out = out + residual
+        return F.relu(out)
+
+
+class ChessNet(nn.Module):
+    """neural_network.py:12-169 (same module construction order, hence the same default init
+    under the same torch seed)."""
+
+    def __init__(self, num_channels=128, num_blocks=4):
+        super().__init__()
+        self.num_channels = num_channels
+        self.num_blocks = num_blocks
+        self.conv1 = nn.Conv2d(15, num_channels, kernel_size=3, padding=1)
+        self.bn1 = nn.BatchNorm2d(num_channels)
+        self.res_blocks = nn.ModuleList([ResidualBlock(num_channels) for _ in range(num_blocks)])
+        self.policy_conv = nn.Conv2d(num_channels, 32, kernel_size=1)
+        self.policy_bn = nn.BatchNorm2d(32)
+        self.policy_fc = nn.Linear(32 * BOARD_SIZE * BOARD_WIDTH, BOARD_SIZE * BOARD_WIDTH * 90)
+        self.value_conv = nn.Conv2d(num_channels, 8, kernel_size=1)
+        self.value_bn = nn.BatchNorm2d(8)
+        self.value_fc1 = nn.Linear(8 * BOARD_SIZE * BOARD_WIDTH, 128)
+        self.value_fc2 = nn.Linear(128, 1)
+
+    def forward(self, x):
+        """neural_network.py:47-71"""
+        x = F.relu(self.bn1(self.conv1(x)))
+        for blk in self.res_blocks:
+            x = blk(x)
+        policy = F.relu(self.policy_bn(self.policy_conv(x)))
+        policy = policy.reshape(policy.size(0), -1)
+        policy = self.policy_fc(policy)
+        value = F.relu(self.value_bn(self.value_conv(x)))
+        value = value.reshape(value.size(0), -1)
+        value = F.relu(self.value_fc1(value))
+        value = torch.tanh(self.value_fc2(value))
+        return policy, value
+
+    # ---- reference-compatible host-side helpers (duck-typed evaluator surface) ----------
+    @staticmethod
+    def encode_board(board, current_player):
+        """neural_network.py:128-146"""
+        encoded = np.zeros((15, BOARD_SIZE, BOARD_WIDTH), dtype=np.float32)
+        for i in range(1, 8):
+            encoded[i - 1] = (board == i).astype(np.float32)
+            encoded[i + 6] = (board == -i).astype(np.float32)
+        encoded[14] = np.ones((BOARD_SIZE, BOARD_WIDTH)) * (current_player == 1)
+        return encoded
+
+    @staticmethod
+    def _logits_to_move_probs(logits, legal_moves):
+        """neural_network.py:148-169"""
+        if len(legal_moves) == 0:
+            return {}
+        idx = [(m[0] * BOARD_WIDTH + m[1]) * 90 + (m[2] * BOARD_WIDTH + m[3]) for m in legal_moves]
+        probs = np.array([logits[i] for i in idx])
+        probs = np.exp(probs - np.max(probs))
+        probs = probs / np.sum(probs)
+        return {move: prob for move, prob in zip(legal_moves, probs)}
+
+    def predict_batch(self, rows):
+        """neural_network.py:96-126"""
+        if len(rows) == 0:
+            return []
+        dev = next(self.parameters()).device
+        states = np.array([self.encode_board(b, p) for b, p, _ in rows])
+        x = torch.from_numpy(states).to(dev)
+        with torch.no_grad():
+            logits, values = self.forward(x)
+        logits = logits.float().cpu().numpy()
+        values = values.float().cpu()
+        return [(self._logits_to_move_probs(logits[i], legal), values[i].item())
+                for i, (_, _, legal) in enumerate(rows)]
+
+    def predict(self, board, current_player, legal_moves):
+        """neural_network.py:73-94"""
+        return self.predict_batch([(board, current_player, legal_moves)])[0]
+
+
+def _fold_bn(conv, bn):
+    """eval-mode BatchNorm folded into the preceding convolution (running stats, foldable per
+    SURVEY.md §8a a12)."""
+    w = conv.weight.detach().double()
+    b = conv.bias.detach().double() if conv.bias is not None else torch.zeros(w.shape[0], dtype=torch.float64)
+    scale = bn.weight.detach().double() / torch.sqrt(bn.running_var.detach().double() + bn.eps)
+    w = w * scale.view(-1, 1, 1, 1)
+    b = (b - bn.running_mean.detach().double()) * scale + bn.bias.detach().double()
+    return w, b
+
+
+class InferenceNet(nn.Module):
+    """Folded, channels-last, low-precision forward of a ChessNet for the engine.
+
+    Input : planes tensor the search kernel wrote — logical shape [G, C_in, 10, 9] with
+            C_in = 15 (NCHW) or 16 (channels-last storage, channel 15 zero).
+    Output: (logits [G, 8100], values [G]) in `dtype`.
+    """
+
+    def __init__(self, net, dtype=torch.bfloat16, c_in=16, device="cuda"):
+        super().__init__()
+        self.dtype = dtype
+        self.c_in = c_in
+        convs = []
+        w, b = _fold_bn(net.conv1, net.bn1)
+        if c_in == 16:
+            w = F.pad(w, (0, 0, 0, 0, 0, 1))
+        convs.append((w, b))
+        for blk in net.res_blocks:
+            convs.append(_fold_bn(blk.conv1, blk.bn1))
+            convs.append(_fold_bn(blk.conv2, blk.bn2))
+        self.n_blocks = len(net.res_blocks)
+        cl = torch.channels_last
+        self.cw = nn.ParameterList([nn.Parameter(w.to(device=device, dtype=dtype).contiguous(memory_format=cl),
+                                                 requires_grad=False) for w, _ in convs])
+        self.cb = nn.ParameterList([nn.Parameter(b.to(device=device, dtype=dtype), requires_grad=False)
+                                    for _, b in convs])
+        # heads: the two 1x1 convolutions share one GEMM (32 + 8 output channels)
+        pw, pb = _fold_bn(net.policy_conv, net.policy_bn)
+        vw, vb = _fold_bn(net.value_conv, net.value_bn)
+        hw = torch.cat([pw, vw], 0)
+        hb = torch.cat([pb, vb], 0)
+        self.hw = nn.Parameter(hw.to(device=device, dtype=dtype).contiguous(memory_format=cl), requires_grad=False)
+        self.hb = nn.Parameter(hb.to(device=device, dtype=dtype), requires_grad=False)
+        # policy FC consumes the NHWC-flattened activation: permute its input columns once
+        # from (c, h, w) order (neural_network.py:62) to (h, w, c)
+        fcw = net.policy_fc.weight.detach().view(-1, 32, 90).permute(0, 2, 1).reshape(-1, 2880)
+        self.pfw = nn.Parameter(fcw.to(device=device, dtype=dtype).contiguous(), requires_grad=False)
+        self.pfb = nn.Parameter(net.policy_fc.bias.detach().to(device=device, dtype=dtype), requires_grad=False)
+        v1 = net.value_fc1.weight.detach().view(-1, 8, 90).permute(0, 2, 1).reshape(-1, 720)
+        self.v1w = nn.Parameter(v1.to(device=device, dtype=dtype).contiguous(), requires_grad=False)
+        self.v1b = nn.Parameter(net.value_fc1.bias.detach().to(device=device, dtype=dtype), requires_grad=False)
+        self.v2w = nn.Parameter(net.value_fc2.weight.detach().to(device=device, dtype=dtype), requires_grad=False)
+        self.v2b = nn.Parameter(net.value_fc2.bias.detach().to(device=device, dtype=dtype), requires_grad=False)
+
+    @torch.no_grad()
+    def forward(self, x):
+        x = F.relu(F.conv2d(x, self.cw[0], self.cb[0], padding=1))
+        for i in range(self.n_blocks):
+            y = F.relu(F.conv2d(x, self.cw[1 + 2 * i], self.cb[1 + 2 * i], padding=1))
+            y = F.conv2d(y, self.cw[2 + 2 * i], self.cb[2 + 2 * i], padding=1)
+            x = F.relu(y + x)
+        h = F.relu(F.conv2d(x, self.hw, self.hb))                  # [G, 40, 10, 9] channels-last
+        h = h.permute(0, 2, 3, 1)                                   # [G, 10, 9, 40] view
+        g = h.shape[0]
+        policy = F.linear(h[..., :32].reshape(g, 2880), self.pfw, self.pfb)
+        v = F.relu(F.linear(h[..., 32:].reshape(g, 720), self.v1w, self.v1b))
+        v = torch.tanh(F.linear(v, self.v2w, self.v2b))
+        return policy, v.reshape(g)

@@ -1,0 +1,128 @@
+"""Host mirror of the reference's self_play.py: MCTS, self_play_game, parallel_self_play,
+InterruptedWithResults — same names, arguments, return types and error behaviour
+(SURVEY.md §8b), backed by the HIP engine (engine.py / libxq_hip.so).
+
+`network` is anything with the reference's predict_batch (duck-typed, self_play.py:143); a
+`chinesechessai_amd.neural_network.ChessNet` living on the GPU takes the fast path
+(TorchNetEvaluator: planes written by the search kernel, logits consumed by the tree kernel).
+"""
+import numpy as np
+
+from . import _lib
+from .chess_env import ChineseChess, decode_move, _sq
+from .config import MAX_MOVES, MCTS_SIMULATIONS
+from .engine import CallbackEvaluator, HashNetEvaluator, SelfPlayEngine, TorchNetEvaluator
+
+
+class InterruptedWithResults(Exception):
+    """self_play.py:12-16"""
+
+    def __init__(self, results):
+        self.results = results
+        super().__init__("Training interrupted by user")
+
+
+def _evaluator_for(network, fast=True):
+    if isinstance(network, (HashNetEvaluator, CallbackEvaluator, TorchNetEvaluator)):
+        return network
+    if fast:
+        try:
+            import torch
+            from .neural_network import ChessNet, InferenceNet
+            if isinstance(network, InferenceNet):
+                return TorchNetEvaluator(network, dtype=network.dtype, channels_last=network.c_in == 16)
+            if isinstance(network, ChessNet) and next(network.parameters()).is_cuda and not network.training:
+                return TorchNetEvaluator(network, dtype=torch.bfloat16)
+        except ImportError:
+            pass
+    return CallbackEvaluator(network)
+
+
+class MCTS:
+    """self_play.py:83-175.  search(env) returns {move: visit_count} over ALL root children in
+    legal-move order (Appendix A13); the tree is rebuilt on every call (self_play.py:98)."""
+
+    def __init__(self, network, num_simulations=None):
+        self.network = network
+        self.default_simulations = num_simulations if num_simulations else MCTS_SIMULATIONS
+        self._engines = {}
+
+    def _engine(self, sims):
+        if sims not in self._engines:
+            self._engines[sims] = SelfPlayEngine(1, sims=sims)
+        return self._engines[sims]
+
+    def search(self, env, num_simulations=None):
+        if num_simulations is None:
+            num_simulations = self.default_simulations
+        eng = self._engine(num_simulations)
+        ev = CallbackEvaluator(self.network) if not isinstance(self.network, HashNetEvaluator) else self.network
+        ev.bind(eng)
+        st = np.zeros((1, _lib.STATE_WORDS), np.int32)          # _copy_env (self_play.py:156-175)
+        st[0, _lib.S_PLAYER] = env.current_player
+        st[0, _lib.S_MOVE_COUNT] = env.move_count
+        st[0, _lib.S_WINNER] = _lib.WINNER_NONE if env.winner is None else env.winner
+        st[0, _lib.S_RED_KING] = _sq(env.red_king_pos)
+        st[0, _lib.S_BLACK_KING] = _sq(env.black_king_pos)
+        st[0, _lib.S_NO_CAPTURE] = env.no_capture_count
+        eng.set_roots(np.ascontiguousarray(env.board, dtype=np.int8).reshape(1, 90), st)
+        eng.search(ev)
+        moves, visits, n = eng.root_visits()
+        return {decode_move(moves[0, j]): int(visits[0, j]) for j in range(int(n[0]))}
+
+
+def _play_batch(network, num_games, temperature, num_simulations, opponent_network, seeds=None, uniforms=None):
+    sims = num_simulations if num_simulations else MCTS_SIMULATIONS
+    ev = _evaluator_for(network)
+    ev_b = _evaluator_for(opponent_network) if opponent_network is not None else None
+    eng = SelfPlayEngine(num_games, sims=sims, temperature=temperature, max_moves=MAX_MOVES,
+                         opponent_mode=opponent_network is not None,
+                         planes_format=getattr(ev, "planes_format", _lib.PLANES_NONE))
+    if ev_b is not None and getattr(ev_b, "planes_format", 0) != getattr(ev, "planes_format", 0):
+        raise ValueError("both networks must use the same planes format")
+    if seeds is None:
+        seeds = np.random.randint(0, 2 ** 31 - 1, size=num_games).astype(np.uint32)
+    try:
+        return eng.play(ev, seeds, opponent_evaluator=ev_b, uniforms=uniforms)
+    finally:
+        eng.close()
+
+
+def self_play_game(network, temperature=1.0, render=False, num_simulations=None, opponent_network=None):
+    """self_play.py:178-312.  Returns ([(board, {move: prob}, z)], winner, end_reason).
+
+    The reference draws one double per ply from NumPy's GLOBAL stream (np.random.choice,
+    self_play.py:242).  The mirror hands the engine the next 70 doubles of that stream and then
+    rewinds it to just after the plies actually played, so a caller that seeds np.random sees
+    the same moves and the same stream position as with the reference."""
+    state = np.random.get_state()
+    uniforms = np.random.random_sample(_lib.MAX_PLIES).reshape(1, _lib.MAX_PLIES)
+    batch = _play_batch(network, 1, temperature, num_simulations, opponent_network,
+                        seeds=np.zeros(1, np.uint32), uniforms=uniforms)
+    np.random.set_state(state)
+    if batch.error[0]:
+        # S <= 8: all root visits are zero -> NaN probabilities
+        raise ValueError("probabilities contain NaN")
+    if batch.n_plies[0]:
+        np.random.random_sample(int(batch.n_plies[0]))
+    if render:
+        env = ChineseChess()
+        for i in range(int(batch.n_plies[0])):
+            mv = decode_move(batch.chosen[0, i])
+            env.make_move(mv)
+            env.render()
+            print(f"走法: {mv}, 即时奖励: {batch.step_reward[0, i]:.2f}")
+    return batch.game_data(0), int(batch.winner[0]), batch.end_reason(0)
+
+
+def parallel_self_play(network, num_games, temperature=1.0, num_simulations=None, num_workers=4,
+                       opponent_network=None, seeds=None):
+    """self_play.py:368-469.  The reference's process pool becomes G concurrent games on the GPU;
+    `num_workers` is accepted and ignored.  Results come back in game order (the reference's
+    order is arbitrary: imap_unordered).  Ctrl-C raises InterruptedWithResults(results) with the
+    games finished so far (none while the batch is in flight: games advance in lock-step)."""
+    try:
+        batch = _play_batch(network, num_games, temperature, num_simulations, opponent_network, seeds=seeds)
+    except KeyboardInterrupt:
+        raise InterruptedWithResults([])
+    return batch.results()

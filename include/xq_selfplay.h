@@ -5,7 +5,7 @@
  * for this hot path is the Python call surface of chess_env.py / self_play.py
  * (SURVEY.md §8b).  The entry points below are what a ctypes binding of THAT surface needs;
  * each cites the reference interface it replaces.  The reference-side stub a maintainer would
- * add is shown in INTEGRATION.md; the in-tree host mirror is chinesechessai_amd/*.py.
+ * add is shown in INTEGRATION.md; the in-tree host mirror is the chinesechessai_amd package.
  *
  * Conventions: extern "C", plain pointers and sizes, no exceptions across the boundary, return
  * 0 on success or a negative XQ_E_* code; xq_last_error() gives the message.  Handles are
@@ -131,6 +131,11 @@ int  xq_engine_set_pow_table(xq_engine *e, const double *table_host, int n);
  * private MT19937 stream exactly as np.random.seed(seed) would (self_play.py:242 draws one
  * double per ply from it). */
 int  xq_engine_new_games(xq_engine *e, const uint32_t *seeds_host);
+
+/* Replace the per-game uniform streams: uniforms_host[g][ply] is the double np.random.choice
+ * consumes at that ply (self_play.py:242).  Lets the host mirror draw from NumPy's GLOBAL stream
+ * exactly as the reference does (Appendix A14).  Call after xq_engine_new_games. */
+int  xq_engine_set_uniforms(xq_engine *e, const double *uniforms_host /*[G][70]*/);
 
 /* Replace the root states (MCTS.search on caller-provided envs; _copy_env semantics of
  * self_play.py:156-175: board, player, move_count, winner, king caches, no_capture_count). */

@@ -1,0 +1,138 @@
+"""CPU suite for the boundary: the C-ABI library loads and exports every symbol include/*.h
+declares; without a GPU every compute entry point fails loudly (no fallback); host-side logic."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from chinesechessai_amd import _lib
+from chinesechessai_amd.chess_env import decode_move, encode_move, format_end_reason
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    hdr = open(os.path.join(ROOT, "include", "xq_selfplay.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(xq_[a-z_0-9]+)\s*\(", hdr)))
+
+
+def test_library_exports_every_declared_symbol():
+    _lib.build()
+    L = C.CDLL(_lib.LIB_PATH)
+    names = _declared_symbols()
+    assert len(names) >= 28
+    for n in names:
+        assert hasattr(L, n), "missing export: " + n
+    assert set(names) == set(_lib.EXPORTS), set(names) ^ set(_lib.EXPORTS)
+
+
+def test_no_gpu_means_loud_failure():
+    L = _lib.lib()
+    if L.xq_device_count() > 0:
+        pytest.skip("a GPU is visible")
+    cfg = _lib.Config(4, 16, 8, 70, 1.0, 0, 0, 0, 0)
+    h = C.c_void_p()
+    rc = L.xq_engine_create(C.byref(cfg), C.byref(h))
+    assert rc == -3 and b"no HIP device" in L.xq_last_error()
+    from chinesechessai_amd import ChineseChess
+    env = ChineseChess()                       # building the start position is data, not compute
+    with pytest.raises(_lib.XqError):
+        env.get_legal_moves()
+    with pytest.raises(_lib.XqError):
+        env.make_move((6, 0, 5, 0))
+    from chinesechessai_amd.engine import SelfPlayEngine
+    with pytest.raises(_lib.XqError):
+        SelfPlayEngine(4)
+
+
+def test_bad_arguments_are_rejected():
+    L = _lib.lib()
+    assert L.xq_engine_create(None, None) == -1
+    cfg = _lib.Config(0, 16, 8, 70, 1.0, 0, 0, 0, 0)
+    h = C.c_void_p()
+    assert L.xq_engine_create(C.byref(cfg), C.byref(h)) == -1
+    assert L.xq_rules_legal_moves(0, None, None, None, None, None, None) == -1
+    assert L.xq_engine_new_games(None, None) == -1
+
+
+def test_product_package_never_imports_the_oracle():
+    """oracle/ is test infrastructure: nothing under chinesechessai_amd/ may import, link or
+    execute it."""
+    pkg = os.path.join(ROOT, "chinesechessai_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(import|from|#\s*include)\b[^\n]*(xq_oracle|\boracle\b)", src, flags=re.M), (dirpath, f)
+                assert "libxq_oracle" not in src and "xqo_" not in src, (dirpath, f)
+
+
+def test_move_encoding_and_reasons():
+    assert encode_move((7, 1, 7, 2)) == (7 * 9 + 1) * 90 + 7 * 9 + 2
+    for m in (0, 1, 8099, 5731):
+        assert encode_move(decode_move(m)) == m
+    # index identity with the policy head (neural_network.py:160)
+    fr, fc, tr, tc = 6, 4, 5, 4
+    assert encode_move((fr, fc, tr, tc)) == (fr * 9 + fc) * 90 + (tr * 9 + tc)
+    assert format_end_reason(1, 1, 0) == "红方吃掉对方将帅"
+    assert format_end_reason(1, -1, 0) == "黑方吃掉对方将帅"
+    assert format_end_reason(2, -1, 0) == "将死黑方"
+    assert format_end_reason(3, 0, 0) == "三次重复局面判和"
+    assert format_end_reason(4, 0, 0) == "50回合无吃子判和"
+    assert format_end_reason(5, 1, 0) == "困毙红方"
+    assert format_end_reason(6, -1, 0) == "长将判负(黑方)"
+    assert format_end_reason(8, 0, 70) == "超过70步判和"
+    assert format_end_reason(0, 0, 0) is None
+
+
+def test_gamebatch_pi_matches_reference_formula():
+    from chinesechessai_amd.engine import GameBatch
+    b = GameBatch(1, 0.5)
+    b.n_samples = np.array([1])
+    b.s_n = np.array([[3]], np.uint8)
+    b.s_moves = np.zeros((1, 1, 128), np.uint16)
+    b.s_moves[0, 0, :3] = [5731, 5732, 5733]
+    b.s_counts = np.zeros((1, 1, 128), np.uint16)
+    b.s_counts[0, 0, :3] = [8, 0, 2]
+    b.s_board = np.zeros((1, 1, 90), np.int8)
+    b.s_z = np.array([[0.25]])
+    (board, pi, z), = b.game_data(0)
+    c = np.array([8, 0, 2]) ** (1.0 / 0.5)
+    assert list(pi.values()) == list(c / c.sum()) and z == 0.25
+    assert all(isinstance(v, np.float64) for v in pi.values())
+    b.temperature = 0.001
+    (_, pi, _), = b.game_data(0)
+    assert list(pi.values()) == [1.0, 0.0, 0.0]
+
+
+def test_chessnet_state_dict_keys_and_shapes():
+    import torch
+    from chinesechessai_amd.neural_network import ChessNet, InferenceNet
+    net = ChessNet()
+    keys = set(net.state_dict().keys())
+    for k in ("conv1.weight", "bn1.running_mean", "res_blocks.3.conv2.bias", "policy_conv.weight", "policy_bn.weight",
+              "policy_fc.weight", "value_conv.weight", "value_bn.bias", "value_fc1.weight", "value_fc2.bias"):
+        assert k in keys
+    assert sum(p.numel() for p in net.parameters()) == 24634141
+    assert net.policy_fc.weight.shape == (8100, 2880)
+    # folded channels-last inference net == eval-mode module (fp32, CPU)
+    torch.manual_seed(3)
+    small = ChessNet(num_channels=16, num_blocks=2)
+    with torch.no_grad():
+        for m in small.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.uniform_(-0.3, 0.3); m.running_var.uniform_(0.5, 2.0)
+                m.weight.uniform_(0.5, 1.5); m.bias.uniform_(-0.2, 0.2)
+    small.eval()
+    x = torch.randn(5, 15, 10, 9)
+    with torch.no_grad():
+        p0, v0 = small(x)
+    for c_in in (15, 16):
+        inet = InferenceNet(small, dtype=torch.float32, c_in=c_in, device="cpu")
+        xi = torch.nn.functional.pad(x, (0, 0, 0, 0, 0, 1)) if c_in == 16 else x
+        xi = xi.contiguous(memory_format=torch.channels_last)
+        p1, v1 = inet(xi)
+        assert torch.allclose(p0, p1, atol=2e-5, rtol=1e-4) and torch.allclose(v0.reshape(-1), v1, atol=1e-5)

@@ -1,0 +1,432 @@
+"""GPU parity tests (run with `-m gpu` on an MI355X): the HIP path, called through the C ABI
+(libxq_hip.so), against the CPU oracle on the same seeded inputs and against the golden vectors
+captured from the reference.  Integer/index results and float64 rewards/z are compared
+bit-for-bit; only the real-network priors use a tolerance (stated in the test)."""
+import json
+import os
+import struct
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(x):
+    return struct.pack("<d", float(x))
+
+
+@pytest.fixture(scope="module")
+def L():
+    from chinesechessai_amd import _lib
+    lib = _lib.lib()
+    assert lib.xq_device_count() > 0, "no GPU visible"
+    assert lib.xq_device_ok(0) == 1, "not a gfx950 device"
+    return lib
+
+
+@pytest.fixture(scope="module")
+def rules(golden_dir):
+    return np.load(os.path.join(golden_dir, "rules_random.npz"))
+
+
+def _legal_batch(L, boards, player, rk, bk):
+    from chinesechessai_amd import _lib
+    n = len(player)
+    moves = np.zeros((n, 128), np.uint16)
+    counts = np.zeros(n, np.int32)
+    _lib.check(L.xq_rules_legal_moves(n, _lib.ptr(np.ascontiguousarray(boards, np.int8)),
+                                      _lib.ptr(np.ascontiguousarray(player, np.int32)),
+                                      _lib.ptr(np.ascontiguousarray(rk, np.int32)),
+                                      _lib.ptr(np.ascontiguousarray(bk, np.int32)),
+                                      _lib.ptr(moves), _lib.ptr(counts)))
+    return moves, counts
+
+
+def test_legal_moves_golden_rows(L, rules):
+    """G1: 5194 positions from the reference -> identical ordered legal-move lists."""
+    d = rules
+    moves, counts = _legal_batch(L, d["board"], d["player"], d["red_king"], d["black_king"])
+    assert np.array_equal(counts, d["nlegal"])
+    for i in range(len(counts)):
+        assert np.array_equal(moves[i, :counts[i]], d["legal"][i, :counts[i]]), i
+    assert counts.max() >= 55
+
+
+def test_edge_boards(L, golden_dir):
+    """Reference unit-test boards (stale king caches) and Appendix-A quirk positions."""
+    from chinesechessai_amd import _lib
+    cases = json.load(open(os.path.join(golden_dir, "rules_edge.json")))
+    n = len(cases)
+    boards = np.array([c["board"] for c in cases], np.int8)
+    player = np.array([c["player"] for c in cases], np.int32)
+    rk = np.array([c["red_king"] for c in cases], np.int32)
+    bk = np.array([c["black_king"] for c in cases], np.int32)
+    moves, counts = _legal_batch(L, boards, player, rk, bk)
+    a, b, f = (np.zeros(n, np.int32) for _ in range(3))
+    _lib.check(L.xq_rules_query(n, _lib.ptr(boards), _lib.ptr(player), _lib.ptr(rk), _lib.ptr(bk),
+                                _lib.ptr(a), _lib.ptr(b), _lib.ptr(f)))
+    for i, c in enumerate(cases):
+        assert moves[i, :counts[i]].tolist() == c["legal"], c["name"]
+        assert bool(a[i]) == c["in_check_red"] and bool(b[i]) == c["in_check_black"], c["name"]
+        assert bool(f[i]) == c["facing"], c["name"]
+    # make_move of every legal move of every edge board, one batch
+    rows = [(i, m) for i, c in enumerate(cases) for m in c["moves"]]
+    nb = len(rows)
+    bb = np.stack([boards[i] for i, _ in rows]).copy()
+    st = np.zeros((nb, 10), np.int32)
+    for j, (i, m) in enumerate(rows):
+        st[j, :7] = [player[i], 0, 2, rk[i], bk[i], 0, 0]
+    mv = np.array([m["move"] for _, m in rows], np.int32)
+    out = _make_move_batch(L, bb, st, mv, None, None)
+    for j, (i, m) in enumerate(rows):
+        assert bits(out["reward"][j]) == bits(m["reward"]), (cases[i]["name"], m)
+        assert bool(out["done"][j]) == m["done"] and bool(out["is_check"][j]) == m["is_check"]
+        assert st[j, 2] == m["winner"] and st[j, 3] == m["rk"] and st[j, 4] == m["bk"]
+        if m["done"]:
+            assert st[j, 7] == m["reason"]
+
+
+def _make_move_batch(L, boards, state, move, pos_hist, chk_hist, n_hist=None, n_chk=None):
+    from chinesechessai_amd import _lib
+    n = len(move)
+    if pos_hist is None:
+        stride = 1
+        pos_hist = np.zeros((n, 1), np.uint64)
+        chk_hist = np.zeros((n, 1), np.uint8)
+        n_hist = np.zeros(n, np.int32)
+        n_chk = np.zeros(n, np.int32)
+    else:
+        stride = pos_hist.shape[1]
+    out = dict(reward=np.zeros(n, np.float64), done=np.zeros(n, np.int32), is_check=np.zeros(n, np.int32),
+               key=np.zeros(n, np.uint64), next_moves=np.zeros((n, 128), np.uint16), next_n=np.zeros(n, np.int32))
+    _lib.check(L.xq_rules_make_move(n, _lib.ptr(boards), _lib.ptr(state), _lib.ptr(move), _lib.ptr(pos_hist),
+                                    _lib.ptr(n_hist), _lib.ptr(chk_hist), _lib.ptr(n_chk), stride,
+                                    _lib.ptr(out["reward"]), _lib.ptr(out["done"]), _lib.ptr(out["is_check"]),
+                                    _lib.ptr(out["key"]), _lib.ptr(out["next_moves"]), _lib.ptr(out["next_n"])))
+    return out
+
+
+def test_make_move_golden_trajectories(L, rules):
+    """G2: the 48 recorded games replayed ply by ply through xq_rules_make_move (all games of a ply
+    in one launch, histories carried by the caller): rewards bit-exact, terminal cascade, caches,
+    counters, plus the legal moves of the next position."""
+    d = rules
+    games = np.unique(d["game"])
+    idx = {g: np.where(d["game"] == g)[0] for g in games}
+    maxlen = max(len(v) for v in idx.values())
+    ng = len(games)
+    boards = np.stack([d["board"][idx[g][0]] for g in games]).copy()
+    state = np.zeros((ng, 10), np.int32)
+    state[:, 0] = 1; state[:, 2] = 2; state[:, 3] = 85; state[:, 4] = 4
+    ph = np.zeros((ng, maxlen + 1), np.uint64)
+    ch = np.zeros((ng, maxlen + 1), np.uint8)
+    nh = np.zeros(ng, np.int32)
+    for t in range(maxlen):
+        live = [k for k, g in enumerate(games) if t < len(idx[g])]
+        rows = [idx[games[k]][t] for k in live]
+        b = boards[live].copy()
+        s = state[live].copy()
+        assert np.array_equal(b, d["board"][rows]), t
+        mv = d["move"][rows].astype(np.int32)
+        out = _make_move_batch(L, b, s, mv, ph[live].copy(), ch[live].copy(), nh[live].copy(), nh[live].copy())
+        for j, (k, r) in enumerate(zip(live, rows)):
+            assert bits(out["reward"][j]) == bits(d["reward"][r]), (r, out["reward"][j], d["reward"][r])
+            assert bool(out["done"][j]) == bool(d["done"][r]), r
+            assert bool(out["is_check"][j]) == bool(d["is_check"][r]), r
+            assert s[j, 0] == -d["player"][r] and s[j, 1] == d["move_count"][r] + 1
+            assert s[j, 2] == d["winner_after"][r], r
+            assert s[j, 3] == d["rk_after"][r] and s[j, 4] == d["bk_after"][r]
+            assert s[j, 5] == d["nc_after"][r] and s[j, 6] == d["cc_after"][r]
+            if d["done"][r]:
+                assert s[j, 7] == d["reason"][r], r
+                if d["reason"][r] in (1, 2, 5, 6):
+                    assert s[j, 8] == d["reason_side"][r]
+                if d["reason"][r] == 8:
+                    assert s[j, 9] == d["reason_count"][r]
+            # next position's legal moves must equal the next recorded row's list
+            if t + 1 < len(idx[games[k]]):
+                r2 = idx[games[k]][t + 1]
+                assert out["next_moves"][j, :out["next_n"][j]].tolist() == d["legal"][r2, :d["nlegal"][r2]].tolist(), r
+            boards[k] = b[j]
+            state[k] = s[j]
+            ph[k, nh[k]] = out["key"][j]
+            ch[k, nh[k]] = out["is_check"][j]
+            nh[k] += 1
+
+
+def test_known_answers_adapter(L, golden_dir):
+    """G3 through the host mirror of ChineseChess: 44 ordered initial moves, the 7-ply mate."""
+    from chinesechessai_amd import ChineseChess
+    from chinesechessai_amd.chess_env import encode_move
+    k = json.load(open(os.path.join(golden_dir, "known.json")))
+    env = ChineseChess()
+    lm = env.get_legal_moves()
+    assert [encode_move(m) for m in lm] == k["initial_moves"] and len(lm) == 44
+    assert all(isinstance(x, int) for x in lm[0])
+    from chinesechessai_amd.chess_env import decode_move
+    for mv, r, dn in zip(k["mate_line"], k["mate_rewards"], k["mate_dones"]):
+        (board, player), reward, done = env.make_move(decode_move(mv))
+        assert reward == r and done == dn
+        assert board.dtype == np.int8 and board.shape == (10, 9)
+    assert env.winner == 1 and env.end_reason == "将死黑方" and reward == 200 and isinstance(reward, int)
+    assert len(env.position_history) == 7 and len(env.check_history) == 7 and len(env.chase_history) == 7
+
+
+def test_reference_unit_test_boards_adapter(L):
+    """The reference's own hand-built test boards, with the results its CURRENT code gives
+    (SURVEY.md §4): callers that assign env.board keep the reset king caches."""
+    from chinesechessai_amd import ChineseChess
+    env = ChineseChess()
+    env.board = np.zeros((10, 9), dtype=np.int8)
+    env.board[2, 4] = -1
+    env.board[8, 4] = 1
+    assert env._are_kings_facing() is True       # caches (9,4)/(0,4): open file -> facing
+    env.board[5, 4] = 5
+    assert env._are_kings_facing() is False
+    # test_reward_system.py:14-41 king capture
+    env = ChineseChess()
+    env.board = np.zeros((10, 9), dtype=np.int8)
+    env.board[0, 4] = -1; env.board[0, 1] = 6; env.board[9, 4] = 1
+    env.current_player = 1
+    _, reward, done = env.make_move((0, 1, 0, 4))
+    assert reward == 100 and done and env.winner == 1 and env.end_reason == "红方吃掉对方将帅"
+    assert env.black_king_pos is None
+    # test_perpetual_rules.py:20-50
+    env = ChineseChess()
+    env.check_history = [True, False] * 6
+    assert env._check_perpetual_check() is False
+    env.check_history = [True] * 11 + [False]
+    assert env._check_perpetual_check() is True
+    _, reward, done = env.make_move((6, 0, 5, 0))
+    assert done and reward == -10 and env.winner == 1 and env.end_reason == "长将判负(黑方)"
+
+
+def _hash_games(S, seeds, T=1.0, opponent=False, G=None):
+    from chinesechessai_amd.engine import HashNetEvaluator, SelfPlayEngine
+    eng = SelfPlayEngine(len(seeds), sims=S, temperature=T, opponent_mode=opponent)
+    b = eng.play(HashNetEvaluator(0), np.array(seeds, np.uint32),
+                 opponent_evaluator=HashNetEvaluator(1) if opponent else None)
+    eng.close()
+    return b
+
+
+def _cmp_fixture(b, g, r):
+    from chinesechessai_amd.chess_env import encode_move
+    if r["error"]:
+        assert b.error[g] == 1
+        return
+    assert b.error[g] == 0
+    assert b.n_plies[g] == len(r["moves"]), (r["seed"], r["sims"])
+    assert b.chosen[g, :b.n_plies[g]].tolist() == r["moves"]
+    assert [bits(x) for x in b.step_reward[g, :b.n_plies[g]]] == [bits(x) for x in r["rewards"]]
+    assert b.winner[g] == r["winner"] and b.reason[g] == r["reason"]
+    assert b.n_samples[g] == r["n_samples"]
+    data = b.game_data(g)
+    for i, (board, pi, z) in enumerate(data):
+        assert bits(z) == bits(r["z"][i]), i
+        assert [encode_move(m) for m in pi.keys()] == r["pi_moves"][i]
+        assert [bits(p) for p in pi.values()] == [bits(p) for p in r["pi"][i]], i
+    if not r["opponent"]:
+        for ply in range(b.n_plies[g]):
+            n = b.s_n[g, ply]
+            assert b.s_moves[g, ply, :n].tolist() == [m for m, _ in r["visits"][ply]]
+            assert b.s_counts[g, ply, :n].tolist() == [v for _, v in r["visits"][ply]], (r["seed"], r["sims"], ply)
+    import zlib
+    crc = 0
+    for board, _, _ in data:
+        crc = zlib.crc32(board.tobytes(), crc)
+    assert crc == r["boards_crc"]
+
+
+def test_engine_games_vs_reference_golden(L, golden_dir):
+    """G4: whole self-play games of the HIP engine with the exact HashNet evaluator against the
+    games the unmodified reference played (root visits per ply, sampled moves, rewards, pi, z,
+    outcome, CRC of the sample boards) — S in {8,15,16,24,50}, T in {1, .5, .1, argmax},
+    arena mode."""
+    games = json.load(open(os.path.join(golden_dir, "search_hashnet.json")))
+    groups = {}
+    for r in games:
+        groups.setdefault((r["sims"], r["T"], r["opponent"]), []).append(r)
+    for (S, T, opp), rs in groups.items():
+        b = _hash_games(S, [r["seed"] for r in rs], T=T, opponent=opp)
+        for g, r in enumerate(rs):
+            _cmp_fixture(b, g, r)
+    slow = os.path.join(golden_dir, "search_hashnet_slow.json")
+    if os.path.exists(slow):
+        for r in json.load(open(slow)):
+            b = _hash_games(r["sims"], [r["seed"]], T=r["T"], opponent=r["opponent"])
+            _cmp_fixture(b, 0, r)
+
+
+def test_engine_games_vs_oracle(L):
+    """64 seeded games x S=24 and 32 x S=50: HIP engine == CPU oracle in every recorded field."""
+    from oracle import xq_oracle as xo
+    for S, n in ((24, 64), (50, 32), (100, 4)):
+        seeds = list(range(1000, 1000 + n))
+        b = _hash_games(S, seeds)
+        for g, seed in enumerate(seeds):
+            rc, og = xo.self_play_game(seed, S)
+            assert rc == 0 and b.error[g] == 0
+            assert og.n_plies == b.n_plies[g] and og.winner == b.winner[g] and og.end_reason == b.reason[g]
+            assert list(og.t_move[:og.n_plies]) == b.chosen[g, :og.n_plies].tolist(), (S, seed)
+            for i in range(og.n_samples):
+                k = og.s_nmoves[i]
+                assert list(og.t_visits[i][:k]) == b.s_counts[g, i, :k].tolist(), (S, seed, i)
+                assert list(og.s_moves[i][:k]) == b.s_moves[g, i, :k].tolist()
+                assert bits(og.s_z[i]) == bits(b.s_z[g, i])
+                assert np.array_equal(np.frombuffer(og.s_board[i], dtype=np.int8), b.s_board[g, i])
+
+
+def test_mcts_search_adapter(L):
+    """MCTS(network).search(env) with a reference-style predict_batch object (CallbackEvaluator
+    path: leaves read back, priors written) == oracle search on the same position."""
+    import zlib
+    from chinesechessai_amd import ChineseChess
+    from chinesechessai_amd.self_play import MCTS
+    from chinesechessai_amd.chess_env import encode_move
+    from oracle import xq_oracle as xo
+
+    class HashNet:
+        calls = []
+
+        def predict_batch(self, rows):
+            self.calls.append(len(rows))
+            out = []
+            for board, player, legal in rows:
+                h0 = zlib.crc32(board.tobytes() + bytes([player & 0xff]))
+                probs = {mv: np.float32(((zlib.crc32(bytes(mv), h0) >> 8) % 64 + 1) / 1024) for mv in legal}
+                out.append((probs, ((h0 >> 4) % 65 - 32) / 64))
+            return out
+
+    env = ChineseChess()
+    for mv in [(7, 7, 7, 4), (0, 1, 2, 0), (7, 4, 3, 4)]:
+        env.make_move(mv)
+    net = HashNet()
+    for S in (15, 24, 50):
+        vc = MCTS(net, num_simulations=S).search(env)
+        oe = xo.OracleEnv()
+        for mv in [(7, 7, 7, 4), (0, 1, 2, 0), (7, 4, 3, 4)]:
+            oe.make_move(xo.encode_move(mv))
+        om, ov = oe.search(S)
+        assert [encode_move(m) for m in vc.keys()] == om
+        assert list(vc.values()) == ov
+        assert sum(vc.values()) == S - 8          # A10: the first batch lands on the root
+    assert max(net.calls) == 8                     # rows are passed with the reference's multiplicity
+
+
+def test_planes_and_network_tolerance(L, golden_dir):
+    """G8: planes written by the search kernel == encode_board of the reference; InferenceNet
+    (folded BN, channels-last) vs the reference ChessNet outputs recorded for the same seeded
+    default init.  fp32: |dlogit| <= 2e-4, priors rtol 1e-3; bf16: priors rtol 6e-2 (bf16 has
+    8 bits of mantissa), values atol 3e-2."""
+    import torch
+    from chinesechessai_amd import _lib
+    from chinesechessai_amd.engine import SelfPlayEngine, TorchNetEvaluator
+    from chinesechessai_amd.neural_network import ChessNet
+    d = np.load(os.path.join(golden_dir, "net.npz"))
+    n = len(d["players"])
+    for tag, seed in (("a", 0), ("b", 1)):
+        torch.manual_seed(seed)
+        net = ChessNet()
+        if tag == "b":
+            with torch.no_grad():
+                for m in net.modules():
+                    if isinstance(m, torch.nn.BatchNorm2d):
+                        m.running_mean.uniform_(-0.2, 0.2)
+                        m.running_var.uniform_(0.5, 1.5)
+                        m.weight.uniform_(0.8, 1.2)
+                        m.bias.uniform_(-0.1, 0.1)
+        net.eval()
+        sd = net.state_dict()
+        wsum = np.array([float(sd[k].double().sum()) for k in sorted(sd) if sd[k].dtype.is_floating_point])
+        assert np.allclose(wsum, d["wsum_" + tag], rtol=1e-9, atol=1e-9), "seeded init differs from the fixture's"
+        assert sum(p.numel() for p in net.parameters()) == int(d["n_params"][0]) == 24634141
+        net = net.cuda()
+        for dtype, cl, tol_p, tol_v in ((torch.float32, False, 1e-3, 1e-4), (torch.bfloat16, True, 6e-2, 3e-2),
+                                        (torch.bfloat16, False, 6e-2, 3e-2)):
+            ev = TorchNetEvaluator(net, dtype=dtype, channels_last=cl)
+            eng = SelfPlayEngine(n, sims=16, planes_format=ev.planes_format)
+            ev.bind(eng)
+            st = np.zeros((n, 10), np.int32)
+            st[:, 0] = d["players"]; st[:, 2] = 2
+            for i in range(n):
+                b = d["boards"][i]
+                st[i, 3] = int(np.argmax(b.reshape(90) == 1)); st[i, 4] = int(np.argmax(b.reshape(90) == -1))
+            eng.set_roots(d["boards"].reshape(n, 90), st)
+            _lib.check(eng.L.xq_engine_search_round(eng.h, 0, 0, None, None, ev.planes_ptr()))
+            torch.cuda.synchronize()
+            planes = ev.x.float().cpu().numpy()[:, :15]
+            assert np.array_equal(planes, d["planes"]), "planes != encode_board"
+            if cl:
+                assert float(ev.x[:, 15].abs().sum()) == 0.0
+            kind, a, v = ev.evaluate(eng)
+            torch.cuda.synchronize()
+            logits = ev.logits.float().cpu().numpy()
+            values = ev.values.float().cpu().numpy()
+            for i in range(n):
+                k = d["nlegal"][i]
+                lg = logits[i, d["legal"][i, :k].astype(np.int64)]
+                if dtype == torch.float32:
+                    assert np.abs(lg - d["logits_" + tag][i, :k]).max() <= 2e-4
+                p = np.exp(lg - lg.max()); p /= p.sum()
+                assert np.allclose(p, d["priors_" + tag][i, :k], rtol=tol_p, atol=1e-6), (tag, dtype, i)
+                assert abs(values[i] - d["values_" + tag][i]) <= tol_v
+            eng.close()
+
+
+def test_real_network_game_runs_and_invariants(L):
+    """Statistical parity with the real net is bounded by H2: here the invariants
+    every reference game satisfies — visit totals S-8 per ply (A10), pi sums to 1, z from the
+    table, 70-ply cap — on 64 games driven by the bf16 network."""
+    import torch
+    from chinesechessai_amd.engine import SelfPlayEngine, TorchNetEvaluator
+    from chinesechessai_amd.neural_network import ChessNet
+    torch.manual_seed(0)
+    net = ChessNet(num_blocks=2).cuda().eval()
+    ev = TorchNetEvaluator(net)
+    S = 24
+    eng = SelfPlayEngine(64, sims=S, planes_format=ev.planes_format)
+    b = eng.play(ev, np.arange(64, dtype=np.uint32))
+    assert (b.error == 0).all()
+    for g in range(64):
+        assert 1 <= b.n_plies[g] <= 70
+        for i in range(b.n_samples[g]):
+            n = b.s_n[g, i]
+            assert b.s_counts[g, i, :n].sum() == S - 8
+        if b.reason[g] == 8:
+            assert b.n_plies[g] == 70 and b.winner[g] == 0
+        data = b.game_data(g)
+        assert abs(sum(data[0][1].values()) - 1.0) < 1e-12
+    eng.close()
+
+
+def test_full_size_properties(L):
+    """BASELINE config sizes with the exact evaluator: 4096 games x S=15 (C2) — every game must
+    equal the oracle's game for its seed (S=15 puts all 7 visits on one child, so all games are
+    the same deterministic line: one oracle game checks 4096), plus a checksum-of-checksums over
+    sampled moves; 16384 games x S=50 for 3 plies: visit totals and tree sizes."""
+    import zlib
+    from chinesechessai_amd.engine import HashNetEvaluator, SelfPlayEngine
+    from oracle import xq_oracle as xo
+    G = 4096
+    eng = SelfPlayEngine(G, sims=15)
+    b = eng.play(HashNetEvaluator(), np.arange(G, dtype=np.uint32))
+    eng.close()
+    rc, og = xo.self_play_game(0, 15)
+    ref = list(og.t_move[:og.n_plies])
+    assert (b.n_plies == og.n_plies).all() and (b.winner == og.winner).all()
+    assert (b.chosen[:, :og.n_plies] == np.array(ref, np.uint16)[None, :]).all()
+    assert len({zlib.crc32(b.chosen[g].tobytes()) for g in range(G)}) == 1
+    G = 16384
+    eng = SelfPlayEngine(G, sims=50, max_moves=3)
+    b = eng.play(HashNetEvaluator(), np.arange(G, dtype=np.uint32))
+    eng.close()
+    assert (b.n_plies == 3).all() and (b.error == 0).all()
+    assert (b.s_counts[:, :3].astype(np.int64).sum(axis=2) == 42).all()
+    for g in (0, 1, 777, 16383):
+        rc, og = xo.self_play_game(g, 50, max_moves=3)
+        assert list(og.t_move[:3]) == b.chosen[g, :3].tolist()
+        for i in range(3):
+            k = og.s_nmoves[i]
+            assert list(og.t_visits[i][:k]) == b.s_counts[g, i, :k].tolist()
