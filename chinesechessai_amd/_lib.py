@@ -59,6 +59,28 @@ def build(force=False, verbose=False):
 
 _lib = None
 
+
+def _preload_torch_hip_runtime():
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so / libhsa-runtime64.so.  Two HIP
+    runtimes in one process cannot both own the GPU, so when torch is installed its runtime is
+    loaded first and libxq_hip.so (NEEDED libamdhip64.so.7) binds to that same copy."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    libdir = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+    for name in ("libhsa-runtime64.so", "libamd_comgr.so", "libamdhip64.so"):
+        path = os.path.join(libdir, name)
+        if os.path.exists(path):
+            try:
+                C.CDLL(path, mode=C.RTLD_GLOBAL)
+            except OSError:
+                pass
+
+
 _I8P, _I32P, _U8P, _U16P, _U32P, _U64P, _F32P, _F64P = (C.POINTER(t) for t in (
     C.c_int8, C.c_int32, C.c_uint8, C.c_uint16, C.c_uint32, C.c_uint64, C.c_float, C.c_double))
 
@@ -107,6 +129,7 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise XqError("libxq_hip.so is not built (%s): run `python -c 'import __graft_entry__ as g; g.build()'`; "
                           "the HIP path has no CPU fallback" % LIB_PATH)
+        _preload_torch_hip_runtime()
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(L, name)

@@ -181,7 +181,11 @@ def test_reference_unit_test_boards_adapter(L):
     env.board = np.zeros((10, 9), dtype=np.int8)
     env.board[2, 4] = -1
     env.board[8, 4] = 1
-    assert env._are_kings_facing() is True       # caches (9,4)/(0,4): open file -> facing
+    # test_kings_facing.py:13-33 FAILS against the reference's current code for this reason:
+    # the stale caches (9,4)/(0,4) see the two kings themselves as blockers
+    assert env._are_kings_facing() is False
+    env.red_king_pos, env.black_king_pos = (8, 4), (2, 4)
+    assert env._are_kings_facing() is True
     env.board[5, 4] = 5
     assert env._are_kings_facing() is False
     # test_reward_system.py:14-41 king capture
@@ -416,8 +420,17 @@ def test_full_size_properties(L):
     rc, og = xo.self_play_game(0, 15)
     ref = list(og.t_move[:og.n_plies])
     assert (b.n_plies == og.n_plies).all() and (b.winner == og.winner).all()
-    assert (b.chosen[:, :og.n_plies] == np.array(ref, np.uint16)[None, :]).all()
-    assert len({zlib.crc32(b.chosen[g].tobytes()) for g in range(G)}) == 1
+    # plies 0..68 are seed-independent (one child holds all 7 visits); at ply 69 every child is a
+    # terminal leaf (70-ply cap) whose in-round backups spread the visits, so the seed picks
+    assert og.n_plies == 70
+    assert (b.chosen[:, :69] == np.array(ref[:69], np.uint16)[None, :]).all()
+    assert len({zlib.crc32(b.chosen[g, :69].tobytes()) for g in range(G)}) == 1
+    assert (b.s_counts[:, :70].astype(np.int64).sum(axis=2) == 7).all()
+    for g in (0, 1, 2, 3, 1234, 4095):
+        rc, og2 = xo.self_play_game(g, 15)
+        assert list(og2.t_move[:70]) == b.chosen[g, :70].tolist()
+        k = og2.s_nmoves[69]
+        assert list(og2.t_visits[69][:k]) == b.s_counts[g, 69, :k].tolist()
     G = 16384
     eng = SelfPlayEngine(G, sims=50, max_moves=3)
     b = eng.play(HashNetEvaluator(), np.arange(G, dtype=np.uint32))
