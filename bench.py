@@ -1,0 +1,256 @@
+#!/usr/bin/env python3
+"""bench.py — self-play games/sec at fixed MCTS sims (BASELINE.json metric) on N MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: launched by torch.distributed.run, one rank per GPU, RCCL)
+
+A "step" = one pass of the hot path over one batch: G concurrent games per GPU played from the
+start position to the end (rules -> MCTS -> network leaf evaluation -> (state, pi, z) samples),
+plus — for N > 1 — the epoch-end all-gather of the sample records.  Workload at N=1 =
+BASELINE.json configs[2], the configuration the metric is quoted on (S = 50):
+16,384 concurrent games, 50 sims, 6-block ResNet bf16, random-init weights, synthetic start
+positions, per-game seeds base+g.  Games shard across GPUs with no data-path collective
+(weak scaling: G per GPU fixed).
+
+Prints ONE JSON line (rank 0).  `roofline` = the dominant cost of the step (the network forward,
+MFMA-bound); `roofline_tree` = the dominant hand-written kernel (k_search_round, HBM-bound
+integer work); both measured live with events on the stream the kernels run on.
+`cpu_baseline` = the CPU oracle ("port" of the reference algorithm, net on CPU torch) timed on the
+host cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+
+MFMA_PEAK_BF16_TFLOPS = 2500.0     # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0              # HBM3E spec, same guide (6.3 TB/s achievable)
+
+
+def net_flops_per_row(blocks):
+    """neural_network.py:25-45 shapes: conv1 + 2 convs per block + heads."""
+    conv1 = 2 * 15 * 128 * 9 * 90
+    res = 2 * 128 * 128 * 9 * 90
+    heads = 2 * 128 * 32 * 90 + 2 * 2880 * 8100 + 2 * 128 * 8 * 90 + 2 * 720 * 128 + 2 * 128
+    return conv1 + 2 * blocks * res + heads
+
+
+def tree_bytes_per_descent(b=33.3, lvl=0.86):
+    """Algorithmic HBM bytes of one descent in THIS layout: root board + scalars
+    (64), PUCT reads 16 B/child/level, leaf move list 2b, packed leaf board 48, bf16 NHWC16 planes
+    2880, legal logits gather 2b+2, move list re-read 2b, edge init 22b, backup RMW 24(l+1).
+    b and l are the reference's measured means."""
+    return 64 + 16 * b * lvl + 2 * b + 48 + 2880 + (2 * b + 2) + 2 * b + 22 * b + 24 * (lvl + 1)
+
+
+def tree_traffic(G, S, blocks):
+    """HBM bytes per k_search_round launch from the committed PMC passes (profiles/): FETCH_SIZE +
+    WRITE_SIZE (KB) of separate rocprofv3 --pmc runs of this same workload; None for other configs."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_tree_kernels.json")
+    if not (G == 16384 and S == 50 and blocks == 6 and os.path.exists(path)):
+        return None
+    k = json.load(open(path))["kernels"].get("k_search_round")
+    if not k:
+        return None
+    return (k["FETCH_SIZE_KB_mean_per_launch"] + k["WRITE_SIZE_KB_mean_per_launch"]) * 1024.0
+
+
+# ------------------------------------------------------------------------------------------
+# CPU baseline: the oracle (C restatement of the reference algorithm) with the net on CPU torch
+# ------------------------------------------------------------------------------------------
+def _cpu_worker(args):
+    idx, blocks, sims, threads, plies, barrier = args
+    import torch
+    torch.set_num_threads(threads)
+    from chinesechessai_amd.neural_network import ChessNet
+    from chinesechessai_amd.chess_env import decode_move
+    from oracle import xq_oracle as xo
+    torch.manual_seed(0)
+    net = ChessNet(num_blocks=blocks).eval()
+
+    def fn(ctx, nrows, boards, players, moves, nmoves, priors, values):
+        rows = []
+        for i in range(nrows):
+            b = np.array([boards[i * 90 + k] for k in range(90)], dtype=np.int8).reshape(10, 9)
+            mv = [decode_move(moves[i * 128 + j]) for j in range(nmoves[i])]
+            rows.append((b, int(players[i]), mv))
+        res = net.predict_batch(rows)             # rows keep the reference's multiplicity (<= 8 duplicates)
+        for i, (d, v) in enumerate(res):
+            for j, p in enumerate(d.values()):
+                priors[i * 128 + j] = float(p)
+            values[i] = float(v)
+        return 0
+
+    cb = xo.EVAL_FN(fn)
+    ev = xo.Evaluator(cb, None)
+    xo.lib()
+    barrier.wait()
+    t0 = time.time()
+    rc, g = xo.self_play_game(1000 + idx, sims, eval_red=ev, max_moves=plies)
+    return time.time() - t0, g.n_plies, rc
+
+
+def cpu_baseline(blocks, sims, workers=4, plies=16, max_cores=16):
+    """4 worker processes x 1 game each, mirroring NUM_WORKERS=4 (config.py:48, self_play.py:404),
+    intra-op threads pinned to cores/4 (the reference's unpinned default oversubscribes,
+    BASELINE.md §2).  Bounded sample: the first `plies` plies of each game, scaled to games/s by
+    plies/70 (random-init games run to the 70-ply cap)."""
+    import multiprocessing as mp
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 4)
+    cores = min(cores, max_cores)                 # the box's CPU share for one GPU
+    threads = max(1, cores // workers)
+    ctx = mp.get_context("spawn")
+    mgr = ctx.Manager()
+    barrier = mgr.Barrier(workers)
+    with ctx.Pool(workers) as pool:
+        res = pool.map(_cpu_worker, [(i, blocks, sims, threads, plies, barrier) for i in range(workers)])
+    wall = max(r[0] for r in res)
+    games_equiv = sum(r[1] for r in res if r[2] == 0) / 70.0
+    return {"value": games_equiv / wall, "unit": "games/s", "cores": workers * threads, "kind": "port",
+            "sample": "%d worker processes x the first %d plies of 1 game each (oracle C rules+MCTS, %d sims, "
+                      "%d-block net fp32 on CPU torch, %d threads each, duplicate leaf rows evaluated as the "
+                      "reference does), scaled by plies/70; wall %.1f s" % (workers, plies, sims, blocks, threads, wall)}
+
+
+# ------------------------------------------------------------------------------------------
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--games", type=int, default=16384, help="concurrent games per GPU")
+    ap.add_argument("--sims", type=int, default=50)
+    ap.add_argument("--blocks", type=int, default=6)
+    ap.add_argument("--warmup-plies", type=int, default=0, help="0 = full warmup steps; >0 shortens a warmup step to this many plies")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-plies", type=int, default=0,
+                    help="profiling aid only: stop every step after this many plies (the JSON line is then NOT a benchmark)")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from chinesechessai_amd import _lib
+    from chinesechessai_amd import distributed as xd
+    from chinesechessai_amd.engine import SelfPlayEngine, TorchNetEvaluator
+    from chinesechessai_amd.neural_network import ChessNet
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.cuda.current_device()
+    G, S = args.games, args.sims
+
+    torch.manual_seed(0)                                   # same random-init weights on every rank
+    net = ChessNet(num_blocks=args.blocks).eval().cuda()
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    ev = TorchNetEvaluator(net, dtype=dtype)
+    stream = torch.cuda.current_stream().cuda_stream
+    records = torch.zeros(G * _lib.MAX_PLIES * xd.RECORD_BYTES, dtype=torch.uint8, device="cuda")
+
+    # time the network forward with events on its own (= the engine's) stream
+    fw_events = []
+    orig_eval = ev.evaluate
+
+    def timed_eval(engine):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        out = orig_eval(engine)
+        b.record()
+        fw_events.append((a, b))
+        return out
+
+    def step(eng, base_seed, timed):
+        ev.evaluate = timed_eval if timed else orig_eval
+        seeds = xd.game_seeds(base_seed, G * world, rank, world)
+        eng.play(ev, seeds, read=False)
+        eng.pack_samples(records.data_ptr())
+        if world > 1:
+            xd.all_gather_records(records)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    eng = SelfPlayEngine(G, sims=S, planes_format=ev.planes_format, device=dev, stream=stream)
+    if args.profile_plies > 0:
+        eng.max_moves = args.profile_plies
+    for w in range(args.warmup):
+        saved = eng.max_moves
+        if args.warmup_plies > 0:
+            eng.max_moves = args.warmup_plies
+        step(eng, 7_000_000 + w * G * world, False)
+        eng.max_moves = saved
+    sync()
+    eng.profile(True)
+    t0 = time.time()
+    for k in range(args.steps):
+        step(eng, k * G * world, True)
+    sync()
+    dt = time.time() - t0
+    prof = eng.profile_read()
+    fw_ms = sum(a.elapsed_time(b) for a, b in fw_events)
+    n_fw = len(fw_events)
+    outcomes = eng.read_game_outcomes()
+    t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+
+    if rank == 0:
+        games = G * world * args.steps
+        rows = G                                            # network rows per forward (one per game)
+        fl = net_flops_per_row(args.blocks)
+        net_tflops = (fl * rows * n_fw) / (fw_ms * 1e-3) / 1e12 if fw_ms > 0 else 0.0
+        bpd = tree_bytes_per_descent()
+        tree_gbs = (bpd * G * prof["search_launches"]) / (prof["search_ms"] * 1e-3) / 1e9 if prof["search_ms"] > 0 else 0.0
+        out = {
+            "metric": "self-play games/sec @ 50 MCTS sims" if S == 50 else "self-play games/sec @ %d MCTS sims" % S,
+            "value": games / dt, "unit": "games/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic" if not args.profile_plies else
+            "synthetic; PROFILING RUN truncated to %d plies per step - not a benchmark" % args.profile_plies,
+            "config": {"workload": "BASELINE configs[2]: %d concurrent games/GPU, %d sims, %d-block ResNet %s, "
+                                   "random-init weights, start positions, seeds base+g" % (G, S, args.blocks, args.dtype),
+                       "games_per_gpu": G, "sims": S, "blocks": args.blocks, "max_moves": 70,
+                       "parallelism": "games sharded x%d, all-gather of samples at step end" % world},
+            "roofline": {"bound": "mfma", "achieved": net_tflops, "peak": MFMA_PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": net_tflops / MFMA_PEAK_BF16_TFLOPS, "traffic": None,
+                         "kernel": "network forward (PyTorch-ROCm, %d launches of %d rows, %.3f ms avg)" % (
+                             n_fw, rows, fw_ms / max(n_fw, 1)),
+                         "flops_per_launch": fl * rows},
+            "roofline_tree": {"bound": "hbm", "achieved": tree_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": tree_gbs / HBM_PEAK_GBS, "traffic": tree_traffic(G, S, args.blocks),
+                              "kernel": "k_search_round (%d launches, %.3f ms avg)" % (
+                                  prof["search_launches"], prof["search_ms"] / max(prof["search_launches"], 1)),
+                              "bytes_per_launch": bpd * G},
+            "time_share": {"net_forward_ms": fw_ms, "k_search_round_ms": prof["search_ms"],
+                           "k_play_move_ms": prof["play_ms"], "wall_ms": dt * 1e3},
+            "games": {"mean_plies": float(outcomes["n_plies"].mean()),
+                      "draws_by_cap": int((outcomes["reason"] == 8).sum()), "errors": int(outcomes["error"].sum())},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.blocks, S)
+        print(json.dumps(out))
+    eng.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -117,9 +117,7 @@ class TorchNetEvaluator:
         G = engine.n_games
         step = self.chunk or G
         for s in range(0, G, step):
-            lg, v = self.inet(self.x[s:s + step])
-            self.logits[s:s + step] = lg
-            self.values[s:s + step] = v
+            self.inet(self.x[s:s + step], out_logits=self.logits[s:s + step], out_values=self.values[s:s + step])
         return self.kind, self.logits.data_ptr(), self.values.data_ptr()
 
 

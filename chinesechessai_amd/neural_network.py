@@ -165,7 +165,7 @@ class InferenceNet(nn.Module):
         self.v2b = nn.Parameter(net.value_fc2.bias.detach().to(device=device, dtype=dtype), requires_grad=False)
 
     @torch.no_grad()
-    def forward(self, x):
+    def forward(self, x, out_logits=None, out_values=None):
         x = F.relu(F.conv2d(x, self.cw[0], self.cb[0], padding=1))
         for i in range(self.n_blocks):
             y = F.relu(F.conv2d(x, self.cw[1 + 2 * i], self.cb[1 + 2 * i], padding=1))
@@ -174,7 +174,14 @@ class InferenceNet(nn.Module):
         h = F.relu(F.conv2d(x, self.hw, self.hb))                  # [G, 40, 10, 9] channels-last
         h = h.permute(0, 2, 3, 1)                                   # [G, 10, 9, 40] view
         g = h.shape[0]
-        policy = F.linear(h[..., :32].reshape(g, 2880), self.pfw, self.pfb)
+        hp = h[..., :32].reshape(g, 2880)
+        if out_logits is not None:
+            policy = torch.addmm(self.pfb, hp, self.pfw.t(), out=out_logits)   # no extra 265 MB copy
+        else:
+            policy = F.linear(hp, self.pfw, self.pfb)
         v = F.relu(F.linear(h[..., 32:].reshape(g, 720), self.v1w, self.v1b))
-        v = torch.tanh(F.linear(v, self.v2w, self.v2b))
-        return policy, v.reshape(g)
+        v = torch.tanh(F.linear(v, self.v2w, self.v2b)).reshape(g)
+        if out_values is not None:
+            out_values.copy_(v)
+            v = out_values
+        return policy, v
