@@ -10,7 +10,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libxq_hip.so")
-SOURCES = [os.path.join(CSRC, "xq_engine.hip")]
+SOURCES = [os.path.join(CSRC, "xq_engine.hip"), os.path.join(CSRC, "xq_conv.hip")]
 HEADERS = [os.path.join(CSRC, "xq_device.hpp"), os.path.join(_HERE, "..", "include", "xq_selfplay.h")]
 
 MAX_MOVES = 128
@@ -115,6 +115,8 @@ _SIGNATURES = {
     "xq_engine_read_games": (C.c_int, [C.c_void_p] * 8),
     "xq_engine_read_samples": (C.c_int, [C.c_void_p] * 9),
     "xq_engine_pack_samples": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "xq_conv3x3_nhwc_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_int, C.c_int, C.c_int]),
     "xq_engine_profile": (C.c_int, [C.c_void_p, C.c_int]),
     "xq_engine_profile_read": (C.c_int, [C.c_void_p] * 5),
 }

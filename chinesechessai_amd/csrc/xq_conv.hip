@@ -1,0 +1,297 @@
+// xq_conv.hip — fused 3x3 convolution for the policy/value ResNet on gfx950 (CDNA4 MFMA).
+//
+//   y = relu( conv3x3(x, w) + bias [+ residual] )        x, y, residual: NHWC bf16 [G][10][9][C]
+//
+// replaces, per residual-tower layer, MIOpen's igemm + a bias kernel + a ReLU kernel + a residual
+// add kernel + a layout copy (38.8 % of the round-1 step was those elementwise passes:
+// profiles/r01_bench_c3_kernel_stats.csv).  Reference op: neural_network.py:54,181-187 with
+// eval-mode BatchNorm folded into (w, bias).
+//
+// Mapping (implicit GEMM, D = W · Xᵀ so that the accumulator holds 4 consecutive output channels
+// per lane and the epilogue packs them without cross-lane traffic):
+//   workgroup = 4 waves = 4 boards (a board is the halo unit: zero padding never crosses boards)
+//   wave      = one board: 3 pixel tiles (96 >= 90 pixels) x 4 channel tiles (128) of 32x32,
+//               v_mfma_f32_32x32x16_bf16, 12 accumulators = 192 VGPRs, one wave per SIMD
+//   A operand = weights  [32 cout][16 k]   from LDS, tap slice [128 cout][CIN] double-buffered
+//   B operand = activations [16 k][32 pixels] from LDS, the wave's board [90][CIN] (loaded once,
+//               re-read by the 9 taps with a per-lane validity mask for the zero padding)
+//   both LDS images are XOR-swizzled on the 16-byte chunk index (row & 15) so that ds_read_b128 of
+//   32 rows x 256-B stride is conflict-free (cdna_hip_programming.md §6 Guideline 4).
+//   epilogue: +bias -> bf16 -> the wave's own activation region (now dead) -> coalesced 16-B rows,
+//   residual added in fp32 on the way out.
+#include "../../include/xq_selfplay.h"
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+namespace {
+
+constexpr int PIX = 90;
+constexpr int COUT = 128;
+constexpr int BOARDS_PER_WG = 4;
+
+__device__ __forceinline__ uint32_t pack_bf16x2(float a, float b)
+{
+    // round-to-nearest-even via the hardware conversion (keeps NaN a NaN)
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+    bf16x2 v = { (__bf16)a, (__bf16)b };
+    return *reinterpret_cast<uint32_t *>(&v);
+}
+
+__device__ __forceinline__ float bf16_lo(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf16_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+
+// 16-byte global -> LDS copy without a VGPR round trip (LDS-DMA): the LDS destination is
+// wave-uniform base + lane*16, the global source is per lane, so the XOR swizzle goes on the
+// SOURCE address (cdna_hip_programming.md §5.4 rule 21).
+__device__ __forceinline__ void dma16(const void *gsrc, void *lds_wave_base)
+{
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
+                                     (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
+}
+
+// STAMP = diagnostic build only (tools/bench_conv.py): wave 0 of each workgroup writes s_memtime
+// phase stamps to a buffer of their own; the production instantiation executes no stamp.
+template <int CIN, bool STAMP = false>
+__global__ __launch_bounds__(256, 1) void k_conv3x3(const uint16_t *__restrict__ x, const uint16_t *__restrict__ w,
+                                                    const float *__restrict__ bias, const uint16_t *__restrict__ res,
+                                                    uint16_t *__restrict__ y, int G, int relu,
+                                                    unsigned long long *stamps = nullptr)
+{
+    auto stamp = [&](int slot) {
+        if constexpr (STAMP) {
+            unsigned long long t = __builtin_amdgcn_s_memtime();
+            if (threadIdx.x == 0) stamps[(size_t)blockIdx.x * 16 + slot] = t;
+        }
+    };
+    stamp(0);
+    constexpr int ROWB = CIN * 2;                 // bytes per pixel row / per cout row of a tap slice
+    constexpr int NCH = CIN / 8;                  // 16-byte chunks per row
+    constexpr int SWZ = NCH >= 16 ? 15 : NCH - 1; // chunk swizzle mask
+    constexpr int KSTEPS = CIN / 16;              // k-steps of 16 per tap
+    constexpr int ACT_BYTES = PIX * 256;          // per-board region (also holds the 128-ch output)
+    constexpr int WBUF_BYTES = COUT * ROWB;
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    uint8_t *act = lds;                                            // [4][ACT_BYTES]
+    uint8_t *wbuf = lds + BOARDS_PER_WG * ACT_BYTES;               // [2][WBUF_BYTES]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int board = blockIdx.x * BOARDS_PER_WG + wave;
+    const bool board_ok = board < G;
+    uint8_t *my_act = act + wave * ACT_BYTES;
+
+    // ---- stage tap 0 weights and this wave's board by LDS-DMA (issued back to back, one wait) ----
+    constexpr int WCHUNKS_PER_WAVE = COUT * NCH / 4;        // each wave stages a quarter of a tap slice
+    constexpr int WINSTR = WCHUNKS_PER_WAVE / 64;           // 8 (CIN 128) or 1 (CIN 16)
+    static_assert(WINSTR * 64 == WCHUNKS_PER_WAVE, "tap slice must tile over 4 waves x 64 lanes");
+    auto stage_weights = [&](int tap, int buf) {
+        const uint8_t *src = reinterpret_cast<const uint8_t *>(w) + (size_t)tap * COUT * ROWB;
+#pragma unroll
+        for (int j = 0; j < WINSTR; j++) {
+            const int q0 = (wave * WINSTR + j) * 64;        // first LDS chunk of this instruction
+            const int q = q0 + lane, row = q / NCH, cp = q % NCH;
+            dma16(src + row * ROWB + ((cp ^ (row & SWZ)) * 16), wbuf + buf * WBUF_BYTES + q0 * 16);
+        }
+    };
+    stage_weights(0, 0);
+    if (board_ok) {
+        const uint8_t *src = reinterpret_cast<const uint8_t *>(x) + (size_t)board * PIX * ROWB;
+        constexpr int NI = (PIX * NCH + 63) / 64;
+#pragma unroll
+        for (int j = 0; j < NI; j++) {
+            const int q = j * 64 + lane, p = q / NCH, cp = q % NCH;
+            if (q < PIX * NCH) dma16(src + p * ROWB + ((cp ^ (p & SWZ)) * 16), my_act + j * 1024);
+        }
+    }
+
+    // per-lane geometry of the 3 pixel tiles
+    const int r32 = lane & 31, h = lane >> 5;
+    int opix[3];
+    uint32_t vmask[3];                // bit t = tap t reads a real pixel (zero padding otherwise)
+#pragma unroll
+    for (int nt = 0; nt < 3; nt++) {
+        const int o = nt * 32 + r32;
+        opix[nt] = o;
+        uint32_t m = 0;
+        if (o < PIX) {
+            const int yy = o / 9, xx = o % 9;
+#pragma unroll
+            for (int t = 0; t < 9; t++) {
+                const int dy = t / 3 - 1, dx = t % 3 - 1;
+                if (yy + dy >= 0 && yy + dy < 10 && xx + dx >= 0 && xx + dx < 9) m |= 1u << t;
+            }
+        }
+        vmask[nt] = m;
+    }
+
+    // bias for the 64 output channels this lane owns (registers 4q..4q+3 of channel tile mt):
+    // fetched now, all 16 loads in flight, consumed after the main loop
+    f32x4 bias_r[4][4];
+#pragma unroll
+    for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            bias_r[mt][q] = *reinterpret_cast<const f32x4 *>(bias + mt * 32 + 8 * q + 4 * h);
+
+    f32x16 acc[4][3];
+#pragma unroll
+    for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+        for (int nt = 0; nt < 3; nt++)
+#pragma unroll
+            for (int i = 0; i < 16; i++) acc[mt][nt][i] = 0.f;
+
+    __syncthreads();
+    stamp(1);
+
+    for (int tap = 0; tap < 9; tap++) {
+        const int buf = tap & 1;
+        // prefetch the next tap's weight slice straight into the other LDS buffer (its last
+        // readers finished before the barrier that ended the previous tap)
+        if (tap + 1 < 9) stage_weights(tap + 1, buf ^ 1);
+        const int dy = tap / 3 - 1, dx = tap % 3 - 1, off = dy * 9 + dx;
+        const uint8_t *wb = wbuf + buf * WBUF_BYTES;
+        int sp[3];
+        bool ok[3];
+#pragma unroll
+        for (int nt = 0; nt < 3; nt++) {
+            ok[nt] = (vmask[nt] >> tap) & 1u;
+            sp[nt] = ok[nt] ? opix[nt] + off : 0;
+        }
+#pragma unroll
+        for (int kk = 0; kk < KSTEPS; kk++) {
+            const int c = kk * 2 + h;
+            bf16x8 bfrag[3], afrag[4];
+#pragma unroll
+            for (int nt = 0; nt < 3; nt++) {
+                bf16x8 v = *reinterpret_cast<const bf16x8 *>(my_act + sp[nt] * ROWB + ((c ^ (sp[nt] & SWZ)) * 16));
+                if (!ok[nt]) {
+#pragma unroll
+                    for (int i = 0; i < 8; i++) v[i] = (__bf16)0.0f;
+                }
+                bfrag[nt] = v;
+            }
+#pragma unroll
+            for (int mt = 0; mt < 4; mt++) {
+                const int row = mt * 32 + r32;
+                afrag[mt] = *reinterpret_cast<const bf16x8 *>(wb + row * ROWB + ((c ^ (row & SWZ)) * 16));
+            }
+#pragma unroll
+            for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+                for (int nt = 0; nt < 3; nt++)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[mt], bfrag[nt], acc[mt][nt], 0, 0, 0);
+        }
+        __syncthreads();
+        stamp(2 + tap);
+    }
+
+    // ---- epilogue: D[row = cout][col = pixel]; lane holds pixel r32 of each tile and couts
+    //      mt*32 + 8q + 4h + (0..3) in registers 4q..4q+3
+#pragma unroll
+    for (int mt = 0; mt < 4; mt++) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int c0 = mt * 32 + 8 * q + 4 * h;
+            const f32x4 b4 = bias_r[mt][q];
+#pragma unroll
+            for (int nt = 0; nt < 3; nt++) {
+                const int p = opix[nt];
+                if (p < PIX) {
+                    const float v0 = acc[mt][nt][4 * q + 0] + b4[0], v1 = acc[mt][nt][4 * q + 1] + b4[1];
+                    const float v2 = acc[mt][nt][4 * q + 2] + b4[2], v3 = acc[mt][nt][4 * q + 3] + b4[3];
+                    uint2 pk = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+                    const int chunk = (c0 * 2) / 16, inner = (c0 * 2) % 16;
+                    *reinterpret_cast<uint2 *>(my_act + p * 256 + ((chunk ^ (p & 15)) * 16) + inner) = pk;
+                }
+            }
+        }
+    }
+    // residual rows are fetched up front (all loads in flight together: one wave per SIMD has
+    // nothing else to hide a dependent load behind)
+    constexpr int NO = (PIX * 16 + 63) / 64;                 // 23 row-chunks per lane
+    uint4 rres[NO];
+    const uint4 *rsrc = (res && board_ok) ? reinterpret_cast<const uint4 *>(res + (size_t)board * PIX * COUT) : nullptr;
+    if (rsrc) {
+#pragma unroll
+        for (int j = 0; j < NO; j++) {
+            const int i = j * 64 + lane;
+            rres[j] = (i < PIX * 16) ? rsrc[i] : make_uint4(0, 0, 0, 0);
+        }
+    }
+    __syncthreads();
+    stamp(11);
+    if (board_ok) {
+        uint4 *dst = reinterpret_cast<uint4 *>(y + (size_t)board * PIX * COUT);
+#pragma unroll
+        for (int j = 0; j < NO; j++) {
+            const int i = j * 64 + lane;
+            if (i < PIX * 16) {
+                const int p = i >> 4, c = i & 15;
+                uint4 v = *reinterpret_cast<const uint4 *>(my_act + p * 256 + ((c ^ (p & 15)) * 16));
+                uint32_t wv[4] = { v.x, v.y, v.z, v.w };
+                uint32_t rv[4] = { 0, 0, 0, 0 };
+                if (rsrc) { rv[0] = rres[j].x; rv[1] = rres[j].y; rv[2] = rres[j].z; rv[3] = rres[j].w; }
+                if (rsrc || relu) {
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        float lo = bf16_lo(wv[k]) + bf16_lo(rv[k]), hi = bf16_hi(wv[k]) + bf16_hi(rv[k]);
+                        if (relu) { lo = lo > 0.f ? lo : 0.f; hi = hi > 0.f ? hi : 0.f; }
+                        wv[k] = pack_bf16x2(lo, hi);
+                    }
+                }
+                dst[i] = make_uint4(wv[0], wv[1], wv[2], wv[3]);
+            }
+        }
+    }
+    stamp(12);
+}
+
+}  // namespace
+
+extern "C" int xq_conv3x3_nhwc_bf16(void *stream, const void *x, const void *w, const void *bias, const void *residual,
+                                    void *y, int n_boards, int c_in, int relu)
+{
+    if (!x || !w || !bias || !y || n_boards <= 0 || (c_in != 16 && c_in != 128)) return XQ_E_INVALID;
+    const int grid = (n_boards + BOARDS_PER_WG - 1) / BOARDS_PER_WG;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (c_in == 128) {
+        constexpr int LDS = BOARDS_PER_WG * PIX * 256 + 2 * COUT * 256;
+        static bool attr_set = false;
+        if (!attr_set) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv3x3<128>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return XQ_E_HIP;
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(k_conv3x3<128>, dim3(grid), dim3(256), LDS, s, (const uint16_t *)x, (const uint16_t *)w,
+                           (const float *)bias, (const uint16_t *)residual, (uint16_t *)y, n_boards, relu);
+    } else {
+        constexpr int LDS = BOARDS_PER_WG * PIX * 256 + 2 * COUT * 32;
+        static bool attr_set16 = false;
+        if (!attr_set16) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv3x3<16>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return XQ_E_HIP;
+            attr_set16 = true;
+        }
+        hipLaunchKernelGGL(k_conv3x3<16>, dim3(grid), dim3(256), LDS, s, (const uint16_t *)x, (const uint16_t *)w,
+                           (const float *)bias, (const uint16_t *)residual, (uint16_t *)y, n_boards, relu);
+    }
+    return hipGetLastError() == hipSuccess ? 0 : XQ_E_HIP;
+}
+
+// diagnostic only (not part of the public ABI): phase stamps of the c_in = 128 kernel
+extern "C" int xq_conv3x3_debug_stamps(void *stream, const void *x, const void *w, const void *bias, const void *residual,
+                                       void *y, int n_boards, int relu, void *stamps)
+{
+    constexpr int LDS = BOARDS_PER_WG * PIX * 256 + 2 * COUT * 256;
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv3x3<128, true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return XQ_E_HIP;
+    const int grid = (n_boards + BOARDS_PER_WG - 1) / BOARDS_PER_WG;
+    hipLaunchKernelGGL((k_conv3x3<128, true>), dim3(grid), dim3(256), LDS, reinterpret_cast<hipStream_t>(stream),
+                       (const uint16_t *)x, (const uint16_t *)w, (const float *)bias, (const uint16_t *)residual,
+                       (uint16_t *)y, n_boards, relu, (unsigned long long *)stamps);
+    return hipGetLastError() == hipSuccess ? 0 : XQ_E_HIP;
+}

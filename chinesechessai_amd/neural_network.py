@@ -146,6 +146,14 @@ class InferenceNet(nn.Module):
                                                  requires_grad=False) for w, _ in convs])
         self.cb = nn.ParameterList([nn.Parameter(b.to(device=device, dtype=dtype), requires_grad=False)
                                     for _, b in convs])
+        # hand-written fused conv path: weights as [tap][cout][cin] bf16, bias fp32
+        self.use_hip_conv = (dtype == torch.bfloat16 and c_in == 16 and str(device).startswith("cuda")
+                             and net.conv1.out_channels == 128)
+        self._buf = None
+        if self.use_hip_conv:
+            self.hip_w = [w.permute(2, 3, 0, 1).reshape(9, w.shape[0], w.shape[1]).to(device=device, dtype=dtype).contiguous()
+                          for w, _ in convs]
+            self.hip_b = [b.to(device=device, dtype=torch.float32).contiguous() for _, b in convs]
         # heads: the two 1x1 convolutions share one GEMM (32 + 8 output channels)
         pw, pb = _fold_bn(net.policy_conv, net.policy_bn)
         vw, vb = _fold_bn(net.value_conv, net.value_bn)
@@ -164,13 +172,40 @@ class InferenceNet(nn.Module):
         self.v2w = nn.Parameter(net.value_fc2.weight.detach().to(device=device, dtype=dtype), requires_grad=False)
         self.v2b = nn.Parameter(net.value_fc2.bias.detach().to(device=device, dtype=dtype), requires_grad=False)
 
+    def _tower_hip(self, x):
+        """Residual tower on the hand-written fused conv kernel (csrc/xq_conv.hip): one launch per
+        convolution, bias / residual / ReLU in its epilogue, NHWC bf16 throughout."""
+        from . import _lib
+        L = _lib.lib()
+        g = x.shape[0]
+        stream = torch.cuda.current_stream().cuda_stream
+        xin = x.permute(0, 2, 3, 1)                       # NHWC view of the channels-last storage
+        assert xin.is_contiguous() and xin.shape[-1] == 16
+        if self._buf is None or self._buf[0].shape[0] != g:
+            self._buf = [torch.empty((g, 10, 9, 128), dtype=torch.bfloat16, device=x.device) for _ in range(3)]
+        a, b, c = self._buf
+
+        def conv(src, dst, i, res, cin):
+            _lib.check(L.xq_conv3x3_nhwc_bf16(stream, src.data_ptr(), self.hip_w[i].data_ptr(), self.hip_b[i].data_ptr(),
+                                              res.data_ptr() if res is not None else None, dst.data_ptr(), g, cin, 1))
+        conv(xin, a, 0, None, 16)
+        cur, t1, t2 = a, b, c
+        for i in range(self.n_blocks):
+            conv(cur, t1, 1 + 2 * i, None, 128)
+            conv(t1, t2, 2 + 2 * i, cur, 128)             # relu(conv + bias + residual)
+            cur, t2 = t2, cur
+        return cur.permute(0, 3, 1, 2)                    # logical NCHW, channels-last strides
+
     @torch.no_grad()
     def forward(self, x, out_logits=None, out_values=None):
-        x = F.relu(F.conv2d(x, self.cw[0], self.cb[0], padding=1))
-        for i in range(self.n_blocks):
-            y = F.relu(F.conv2d(x, self.cw[1 + 2 * i], self.cb[1 + 2 * i], padding=1))
-            y = F.conv2d(y, self.cw[2 + 2 * i], self.cb[2 + 2 * i], padding=1)
-            x = F.relu(y + x)
+        if self.use_hip_conv and x.is_cuda:
+            x = self._tower_hip(x)
+        else:
+            x = F.relu(F.conv2d(x, self.cw[0], self.cb[0], padding=1))
+            for i in range(self.n_blocks):
+                y = F.relu(F.conv2d(x, self.cw[1 + 2 * i], self.cb[1 + 2 * i], padding=1))
+                y = F.conv2d(y, self.cw[2 + 2 * i], self.cb[2 + 2 * i], padding=1)
+                x = F.relu(y + x)
         h = F.relu(F.conv2d(x, self.hw, self.hb))                  # [G, 40, 10, 9] channels-last
         h = h.permute(0, 2, 3, 1)                                   # [G, 10, 9, 40] view
         g = h.shape[0]

@@ -208,6 +208,15 @@ typedef struct {
 } xq_sample_record;
 int  xq_engine_pack_samples(xq_engine *e, void *records_dev /* xq_sample_record[G][70] */);
 
+/* ---- network: fused 3x3 convolution of the residual tower (neural_network.py:54,181-187 with the
+ * eval-mode BatchNorm folded into weights and bias):
+ *     y = relu?( conv3x3(x, w) + bias [+ residual] )
+ * x [n_boards][10][9][c_in] bf16 (c_in = 16 or 128), w [9 taps][128 out][c_in] bf16,
+ * bias float32[128], residual / y [n_boards][10][9][128] bf16; all device pointers; residual may
+ * be NULL; y may alias residual but not x.  Launches on `hip_stream`. */
+int  xq_conv3x3_nhwc_bf16(void *hip_stream, const void *x_dev, const void *w_dev, const void *bias_dev,
+                          const void *residual_dev, void *y_dev, int n_boards, int c_in, int relu);
+
 /* ---- measurement: HIP events recorded on the engine's stream around every tree-kernel launch ---- */
 int  xq_engine_profile(xq_engine *e, int enable);
 int  xq_engine_profile_read(xq_engine *e, double *search_ms_total, int64_t *search_launches,
