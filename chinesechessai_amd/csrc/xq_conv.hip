@@ -65,6 +65,10 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3(const uint16_t *__restrict__
         if constexpr (STAMP) {
             unsigned long long t = __builtin_amdgcn_s_memtime();
             if (threadIdx.x == 0) stamps[(size_t)blockIdx.x * 16 + slot] = t;
+            if (slot == 0 || slot == 12) {      // 100 MHz wall clock at both ends -> in-kernel shader clock
+                unsigned long long rt = __builtin_amdgcn_s_memrealtime();
+                if (threadIdx.x == 0) stamps[(size_t)blockIdx.x * 16 + (slot == 0 ? 13 : 14)] = rt;
+            }
         }
     };
     stamp(0);
@@ -77,6 +81,7 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3(const uint16_t *__restrict__
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     uint8_t *act = lds;                                            // [4][ACT_BYTES]
     uint8_t *wbuf = lds + BOARDS_PER_WG * ACT_BYTES;               // [2][WBUF_BYTES]
+    uint8_t *zrow = wbuf + 2 * WBUF_BYTES;                         // 256 zero bytes: the padding "pixel"
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int board = blockIdx.x * BOARDS_PER_WG + wave;
@@ -96,6 +101,7 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3(const uint16_t *__restrict__
             dma16(src + row * ROWB + ((cp ^ (row & SWZ)) * 16), wbuf + buf * WBUF_BYTES + q0 * 16);
         }
     };
+    if (tid < 16) reinterpret_cast<uint4 *>(zrow)[tid] = make_uint4(0, 0, 0, 0);
     stage_weights(0, 0);
     if (board_ok) {
         const uint8_t *src = reinterpret_cast<const uint8_t *>(x) + (size_t)board * PIX * ROWB;
@@ -154,36 +160,40 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3(const uint16_t *__restrict__
         if (tap + 1 < 9) stage_weights(tap + 1, buf ^ 1);
         const int dy = tap / 3 - 1, dx = tap % 3 - 1, off = dy * 9 + dx;
         const uint8_t *wb = wbuf + buf * WBUF_BYTES;
-        int sp[3];
-        bool ok[3];
+        // per-lane row pointers of this tap: a real pixel row, or the zero row for padding
+        // (no per-fragment select, no dependency between the LDS read and the MFMA)
+        const uint8_t *brow[3];
+        int bswz[3];
 #pragma unroll
         for (int nt = 0; nt < 3; nt++) {
-            ok[nt] = (vmask[nt] >> tap) & 1u;
-            sp[nt] = ok[nt] ? opix[nt] + off : 0;
+            const bool ok = (vmask[nt] >> tap) & 1u;
+            const int sp = opix[nt] + off;
+            brow[nt] = ok ? my_act + sp * ROWB : zrow;
+            bswz[nt] = ok ? (sp & SWZ) : 0;
         }
-#pragma unroll
-        for (int kk = 0; kk < KSTEPS; kk++) {
+        auto load_frags = [&](int kk, bf16x8 (&bf)[3], bf16x8 (&af)[4]) {
             const int c = kk * 2 + h;
-            bf16x8 bfrag[3], afrag[4];
 #pragma unroll
-            for (int nt = 0; nt < 3; nt++) {
-                bf16x8 v = *reinterpret_cast<const bf16x8 *>(my_act + sp[nt] * ROWB + ((c ^ (sp[nt] & SWZ)) * 16));
-                if (!ok[nt]) {
-#pragma unroll
-                    for (int i = 0; i < 8; i++) v[i] = (__bf16)0.0f;
-                }
-                bfrag[nt] = v;
-            }
+            for (int nt = 0; nt < 3; nt++)
+                bf[nt] = *reinterpret_cast<const bf16x8 *>(brow[nt] + ((c ^ bswz[nt]) * 16));
 #pragma unroll
             for (int mt = 0; mt < 4; mt++) {
                 const int row = mt * 32 + r32;
-                afrag[mt] = *reinterpret_cast<const bf16x8 *>(wb + row * ROWB + ((c ^ (row & SWZ)) * 16));
+                af[mt] = *reinterpret_cast<const bf16x8 *>(wb + row * ROWB + ((c ^ (row & SWZ)) * 16));
             }
+        };
+        // software pipeline: fragments of k-step kk+1 are in flight while the 12 MFMAs of kk run
+        bf16x8 bfr[2][3], afr[2][4];
+        load_frags(0, bfr[0], afr[0]);
+#pragma unroll
+        for (int kk = 0; kk < KSTEPS; kk++) {
+            const int cur = kk & 1;
+            if (kk + 1 < KSTEPS) load_frags(kk + 1, bfr[cur ^ 1], afr[cur ^ 1]);
 #pragma unroll
             for (int mt = 0; mt < 4; mt++)
 #pragma unroll
                 for (int nt = 0; nt < 3; nt++)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[mt], bfrag[nt], acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[cur][mt], bfr[cur][nt], acc[mt][nt], 0, 0, 0);
         }
         __syncthreads();
         stamp(2 + tap);
@@ -250,16 +260,259 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3(const uint16_t *__restrict__
     stamp(12);
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Variant B: 2 boards per workgroup, 2 workgroups per CU (8 waves, two per SIMD) so that one
+// workgroup's load / store phases and barriers hide behind the other's MFMA work.
+//   wave (b, hc): board b, output-channel half hc -> 3 pixel tiles x 2 channel tiles (96 acc regs)
+//   weights streamed in K-slices of KSL input channels: [128 cout][KSL] double-buffered (32 KB)
+//   LDS per workgroup: 2 x 23,040 (boards / output staging) + 32,768 + 256 = 79,104 B
+// ------------------------------------------------------------------------------------------
+template <int CIN, bool STAMP = false>
+__global__ __launch_bounds__(256, 2) void k_conv3x3_b(const uint16_t *__restrict__ x, const uint16_t *__restrict__ w,
+                                                      const float *__restrict__ bias, const uint16_t *__restrict__ res,
+                                                      uint16_t *__restrict__ y, int G, int relu,
+                                                      unsigned long long *stamps = nullptr)
+{
+    constexpr int NB = 2;
+    constexpr int ROWB = CIN * 2, NCH = CIN / 8;
+    constexpr int ARP = 256 / ROWB >= 1 ? (ROWB >= 256 ? 1 : 256 / ROWB) : 1;     // act rows per 256 B
+    constexpr int KSL = CIN >= 64 ? 64 : CIN;            // input channels per weight stage
+    constexpr int SPT = CIN / KSL;                       // stages per tap
+    constexpr int NSTAGE = 9 * SPT;
+    constexpr int WROWB = KSL * 2, WNCH = KSL / 8;       // weight-slice row bytes / chunks
+    constexpr int WRP = 256 / WROWB;                     // weight rows per 256 B
+    constexpr int KSTEPS = KSL / 16;
+    constexpr int ACT_BYTES = PIX * 256;
+    constexpr int WBUF_BYTES = COUT * WROWB;
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    uint8_t *act = lds;
+    uint8_t *wbuf = lds + NB * ACT_BYTES;
+    uint8_t *zrow = wbuf + 2 * WBUF_BYTES;
+
+    auto stamp = [&](int slot) {
+        if constexpr (STAMP) {
+            unsigned long long t = __builtin_amdgcn_s_memtime();
+            if (threadIdx.x == 0) stamps[(size_t)blockIdx.x * 32 + slot] = t;
+            if (slot == 0 || slot == 23) {
+                unsigned long long rt = __builtin_amdgcn_s_memrealtime();
+                if (threadIdx.x == 0) stamps[(size_t)blockIdx.x * 32 + (slot == 0 ? 24 : 25)] = rt;
+            }
+        }
+    };
+    stamp(0);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wb_ = wave >> 1, hc = wave & 1;            // board within the workgroup, channel half
+    const int board = blockIdx.x * NB + wb_;
+    const bool board_ok = board < G;
+    uint8_t *my_act = act + wb_ * ACT_BYTES;
+
+    auto aswz = [&](int row) { return (row / ARP) & (NCH - 1); };
+    auto wswz = [&](int row) { return (row / WRP) & (WNCH - 1); };
+
+    constexpr int WINSTR = COUT * WNCH / 256;            // DMA instructions per wave per stage (4 or 1)
+    static_assert(WINSTR * 256 == COUT * WNCH, "weight stage must tile over 256 lanes");
+    auto stage_weights = [&](int st, int buf) {
+        const int tap = st / SPT, kb = (st % SPT) * KSL;
+        const uint8_t *src = reinterpret_cast<const uint8_t *>(w) + ((size_t)tap * COUT * CIN + kb) * 2;
+#pragma unroll
+        for (int j = 0; j < WINSTR; j++) {
+            const int q0 = (wave * WINSTR + j) * 64;
+            const int q = q0 + lane, row = q / WNCH, cp = q % WNCH;
+            dma16(src + (size_t)row * ROWB + ((cp ^ wswz(row)) * 16), wbuf + buf * WBUF_BYTES + q0 * 16);
+        }
+    };
+    if (tid < 16) reinterpret_cast<uint4 *>(zrow)[tid] = make_uint4(0, 0, 0, 0);
+    stage_weights(0, 0);
+    if (board_ok) {
+        // the two waves of a board each fetch half of it
+        const uint8_t *src = reinterpret_cast<const uint8_t *>(x) + (size_t)board * PIX * ROWB;
+        constexpr int NCHUNK = PIX * NCH;
+        constexpr int NI = (NCHUNK + 127) / 128;
+#pragma unroll
+        for (int j = 0; j < NI; j++) {
+            const int q0 = (j * 2 + hc) * 64, q = q0 + lane, p = q / NCH, cp = q % NCH;
+            if (q < NCHUNK) dma16(src + p * ROWB + ((cp ^ aswz(p)) * 16), my_act + q0 * 16);
+        }
+    }
+
+    const int r32 = lane & 31, h = lane >> 5;
+    int opix[3];
+    uint32_t vmask[3];
+#pragma unroll
+    for (int nt = 0; nt < 3; nt++) {
+        const int o = nt * 32 + r32;
+        opix[nt] = o;
+        uint32_t m = 0;
+        if (o < PIX) {
+            const int yy = o / 9, xx = o % 9;
+#pragma unroll
+            for (int t = 0; t < 9; t++) {
+                const int dy = t / 3 - 1, dx = t % 3 - 1;
+                if (yy + dy >= 0 && yy + dy < 10 && xx + dx >= 0 && xx + dx < 9) m |= 1u << t;
+            }
+        }
+        vmask[nt] = m;
+    }
+
+    f32x4 bias_r[2][4];
+#pragma unroll
+    for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            bias_r[mt][q] = *reinterpret_cast<const f32x4 *>(bias + hc * 64 + mt * 32 + 8 * q + 4 * h);
+
+    f32x16 acc[2][3];
+#pragma unroll
+    for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+        for (int nt = 0; nt < 3; nt++)
+#pragma unroll
+            for (int i = 0; i < 16; i++) acc[mt][nt][i] = 0.f;
+
+    __syncthreads();
+    stamp(1);
+
+    for (int st = 0; st < NSTAGE; st++) {
+        const int buf = st & 1;
+        if (st + 1 < NSTAGE) stage_weights(st + 1, buf ^ 1);
+        const int tap = st / SPT, cbase = (st % SPT) * (KSL / 8);
+        const int dy = tap / 3 - 1, dx = tap % 3 - 1, off = dy * 9 + dx;
+        const uint8_t *wb = wbuf + buf * WBUF_BYTES;
+        const uint8_t *brow[3];
+        int bswz[3];
+#pragma unroll
+        for (int nt = 0; nt < 3; nt++) {
+            const bool ok = (vmask[nt] >> tap) & 1u;
+            const int sp = opix[nt] + off;
+            brow[nt] = ok ? my_act + sp * ROWB : zrow;
+            bswz[nt] = ok ? aswz(sp) : 0;
+        }
+        auto load_frags = [&](int kk, bf16x8 (&bf)[3], bf16x8 (&af)[2]) {
+            const int cw = kk * 2 + h, ca = cbase + cw;
+#pragma unroll
+            for (int nt = 0; nt < 3; nt++)
+                bf[nt] = *reinterpret_cast<const bf16x8 *>(brow[nt] + ((ca ^ bswz[nt]) * 16));
+#pragma unroll
+            for (int mt = 0; mt < 2; mt++) {
+                const int row = hc * 64 + mt * 32 + r32;
+                af[mt] = *reinterpret_cast<const bf16x8 *>(wb + row * WROWB + ((cw ^ wswz(row)) * 16));
+            }
+        };
+        bf16x8 bfr[2][3], afr[2][2];
+        load_frags(0, bfr[0], afr[0]);
+#pragma unroll
+        for (int kk = 0; kk < KSTEPS; kk++) {
+            const int cur = kk & 1;
+            if (kk + 1 < KSTEPS) load_frags(kk + 1, bfr[cur ^ 1], afr[cur ^ 1]);
+#pragma unroll
+            for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+                for (int nt = 0; nt < 3; nt++)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[cur][mt], bfr[cur][nt], acc[mt][nt], 0, 0, 0);
+        }
+        __syncthreads();
+        if constexpr (STAMP) { if (st < 18) stamp(2 + st); }
+    }
+
+    // ---- epilogue: +bias -> bf16 -> the board's region [pixel][128 cout] (both channel halves) ----
+#pragma unroll
+    for (int mt = 0; mt < 2; mt++) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int c0 = hc * 64 + mt * 32 + 8 * q + 4 * h;
+            const f32x4 b4 = bias_r[mt][q];
+#pragma unroll
+            for (int nt = 0; nt < 3; nt++) {
+                const int p = opix[nt];
+                if (p < PIX) {
+                    const float v0 = acc[mt][nt][4 * q + 0] + b4[0], v1 = acc[mt][nt][4 * q + 1] + b4[1];
+                    const float v2 = acc[mt][nt][4 * q + 2] + b4[2], v3 = acc[mt][nt][4 * q + 3] + b4[3];
+                    uint2 pk = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+                    const int chunk = (c0 * 2) / 16, inner = (c0 * 2) % 16;
+                    *reinterpret_cast<uint2 *>(my_act + p * 256 + ((chunk ^ (p & 15)) * 16) + inner) = pk;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    stamp(21);
+    if (board_ok) {
+        // each wave streams half of its board's rows out (coalesced 16-B chunks), residual + ReLU
+        uint4 *dst = reinterpret_cast<uint4 *>(y + (size_t)board * PIX * COUT);
+        const uint4 *rsrc = res ? reinterpret_cast<const uint4 *>(res + (size_t)board * PIX * COUT) : nullptr;
+        constexpr int NO = (PIX * 16 + 127) / 128;          // 12 chunks per lane
+        uint4 rres[NO];
+        if (rsrc) {
+#pragma unroll
+            for (int j = 0; j < NO; j++) {
+                const int i = (j * 2 + hc) * 64 + lane;
+                rres[j] = (i < PIX * 16) ? rsrc[i] : make_uint4(0, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NO; j++) {
+            const int i = (j * 2 + hc) * 64 + lane;
+            if (i < PIX * 16) {
+                const int p = i >> 4, c = i & 15;
+                uint4 v = *reinterpret_cast<const uint4 *>(my_act + p * 256 + ((c ^ (p & 15)) * 16));
+                uint32_t wv[4] = { v.x, v.y, v.z, v.w };
+                uint32_t rv[4] = { 0, 0, 0, 0 };
+                if (rsrc) { rv[0] = rres[j].x; rv[1] = rres[j].y; rv[2] = rres[j].z; rv[3] = rres[j].w; }
+                if (rsrc || relu) {
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        float lo = bf16_lo(wv[k]) + bf16_lo(rv[k]), hi = bf16_hi(wv[k]) + bf16_hi(rv[k]);
+                        if (relu) { lo = lo > 0.f ? lo : 0.f; hi = hi > 0.f ? hi : 0.f; }
+                        wv[k] = pack_bf16x2(lo, hi);
+                    }
+                }
+                dst[i] = make_uint4(wv[0], wv[1], wv[2], wv[3]);
+            }
+        }
+    }
+    stamp(23);
+}
+
 }  // namespace
+
+static int g_conv_variant = 1;      // 0 = 4 boards / workgroup, 1 workgroup / CU; 1 = variant B (default)
+
+// diagnostic only (not part of the public ABI)
+extern "C" void xq_conv3x3_set_variant(int v) { g_conv_variant = v; }
+
+template <int CIN>
+static int launch_b(hipStream_t s, const void *x, const void *w, const void *bias, const void *residual, void *y,
+                    int n_boards, int relu)
+{
+    constexpr int KSL = CIN >= 64 ? 64 : CIN;
+    constexpr int LDS = 2 * PIX * 256 + 2 * COUT * KSL * 2 + 256;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv3x3_b<CIN, false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return XQ_E_HIP;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_conv3x3_b<CIN, false>), dim3((n_boards + 1) / 2), dim3(256), LDS, s, (const uint16_t *)x,
+                       (const uint16_t *)w, (const float *)bias, (const uint16_t *)residual, (uint16_t *)y, n_boards,
+                       relu, (unsigned long long *)nullptr);
+    return hipGetLastError() == hipSuccess ? 0 : XQ_E_HIP;
+}
 
 extern "C" int xq_conv3x3_nhwc_bf16(void *stream, const void *x, const void *w, const void *bias, const void *residual,
                                     void *y, int n_boards, int c_in, int relu)
 {
     if (!x || !w || !bias || !y || n_boards <= 0 || (c_in != 16 && c_in != 128)) return XQ_E_INVALID;
+    if (g_conv_variant == 1) {
+        hipStream_t sb = reinterpret_cast<hipStream_t>(stream);
+        return c_in == 128 ? launch_b<128>(sb, x, w, bias, residual, y, n_boards, relu)
+                           : launch_b<16>(sb, x, w, bias, residual, y, n_boards, relu);
+    }
     const int grid = (n_boards + BOARDS_PER_WG - 1) / BOARDS_PER_WG;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (c_in == 128) {
-        constexpr int LDS = BOARDS_PER_WG * PIX * 256 + 2 * COUT * 256;
+        constexpr int LDS = BOARDS_PER_WG * PIX * 256 + 2 * COUT * 256 + 256;
         static bool attr_set = false;
         if (!attr_set) {
             if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv3x3<128>),
@@ -269,7 +522,7 @@ extern "C" int xq_conv3x3_nhwc_bf16(void *stream, const void *x, const void *w, 
         hipLaunchKernelGGL(k_conv3x3<128>, dim3(grid), dim3(256), LDS, s, (const uint16_t *)x, (const uint16_t *)w,
                            (const float *)bias, (const uint16_t *)residual, (uint16_t *)y, n_boards, relu);
     } else {
-        constexpr int LDS = BOARDS_PER_WG * PIX * 256 + 2 * COUT * 32;
+        constexpr int LDS = BOARDS_PER_WG * PIX * 256 + 2 * COUT * 32 + 256;
         static bool attr_set16 = false;
         if (!attr_set16) {
             if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv3x3<16>),
@@ -286,12 +539,25 @@ extern "C" int xq_conv3x3_nhwc_bf16(void *stream, const void *x, const void *w, 
 extern "C" int xq_conv3x3_debug_stamps(void *stream, const void *x, const void *w, const void *bias, const void *residual,
                                        void *y, int n_boards, int relu, void *stamps)
 {
-    constexpr int LDS = BOARDS_PER_WG * PIX * 256 + 2 * COUT * 256;
+    constexpr int LDS = BOARDS_PER_WG * PIX * 256 + 2 * COUT * 256 + 256;
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv3x3<128, true>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return XQ_E_HIP;
     const int grid = (n_boards + BOARDS_PER_WG - 1) / BOARDS_PER_WG;
     hipLaunchKernelGGL((k_conv3x3<128, true>), dim3(grid), dim3(256), LDS, reinterpret_cast<hipStream_t>(stream),
                        (const uint16_t *)x, (const uint16_t *)w, (const float *)bias, (const uint16_t *)residual,
                        (uint16_t *)y, n_boards, relu, (unsigned long long *)stamps);
+    return hipGetLastError() == hipSuccess ? 0 : XQ_E_HIP;
+}
+
+// diagnostic only: phase stamps of variant B (c_in = 128): 32 u64 per workgroup
+extern "C" int xq_conv3x3_debug_stamps_b(void *stream, const void *x, const void *w, const void *bias, const void *residual,
+                                         void *y, int n_boards, int relu, void *stamps)
+{
+    constexpr int LDS = 2 * PIX * 256 + 2 * COUT * 64 * 2 + 256;
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv3x3_b<128, true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return XQ_E_HIP;
+    hipLaunchKernelGGL((k_conv3x3_b<128, true>), dim3((n_boards + 1) / 2), dim3(256), LDS,
+                       reinterpret_cast<hipStream_t>(stream), (const uint16_t *)x, (const uint16_t *)w, (const float *)bias,
+                       (const uint16_t *)residual, (uint16_t *)y, n_boards, relu, (unsigned long long *)stamps);
     return hipGetLastError() == hipSuccess ? 0 : XQ_E_HIP;
 }

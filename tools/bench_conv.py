@@ -1,9 +1,10 @@
 """Micro-benchmark + check of the fused conv kernel against torch (run on the GPU box)."""
+import ctypes as C
 import os
 import sys
-import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
 import torch
 import torch.nn.functional as F
 from chinesechessai_amd import _lib
@@ -11,74 +12,75 @@ from chinesechessai_amd import _lib
 L = _lib.lib()
 torch.manual_seed(0)
 G = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
-for cin in (128, 16):
-    x = (torch.randn(G, 10, 9, cin, device="cuda") * 0.5).bfloat16()
-    w = (torch.randn(128, cin, 3, 3, device="cuda") * (1.0 / (3 * cin ** 0.5))).bfloat16()
-    b = torch.randn(128, device="cuda") * 0.1
-    r = (torch.randn(G, 10, 9, 128, device="cuda") * 0.5).bfloat16()
-    wk = w.permute(2, 3, 0, 1).reshape(9, 128, cin).contiguous()
-    y = torch.empty(G, 10, 9, 128, device="cuda", dtype=torch.bfloat16)
-    st = torch.cuda.current_stream().cuda_stream
-    for use_res in (False, True):
-        _lib.check(L.xq_conv3x3_nhwc_bf16(st, x.data_ptr(), wk.data_ptr(), b.data_ptr(), r.data_ptr() if use_res else None,
-                                          y.data_ptr(), G, cin, 1))
-        torch.cuda.synchronize()
-        n = min(G, 512)
-        ref = F.conv2d(x[:n].permute(0, 3, 1, 2).float(), w.float(), b, padding=1)
-        ref = ref.bfloat16().float()           # the kernel rounds conv+bias to bf16 before the residual add
-        if use_res:
-            ref = ref + r[:n].permute(0, 3, 1, 2).float()
-        ref = torch.relu(ref).permute(0, 2, 3, 1)
-        err = (y[:n].float() - ref).abs().max().item()
-        print("cin=%d res=%d max_abs_err=%.4g (ref max %.3g)" % (cin, use_res, err, ref.abs().max().item()))
+st = torch.cuda.current_stream().cuda_stream
+
+
+def timeit(fn, it=20):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     for _ in range(3):
-        L.xq_conv3x3_nhwc_bf16(st, x.data_ptr(), wk.data_ptr(), b.data_ptr(), r.data_ptr(), y.data_ptr(), G, cin, 1)
+        fn()
     e0.record()
-    it = 20
     for _ in range(it):
-        L.xq_conv3x3_nhwc_bf16(st, x.data_ptr(), wk.data_ptr(), b.data_ptr(), r.data_ptr(), y.data_ptr(), G, cin, 1)
+        fn()
     e1.record()
     torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / it
+    return e0.elapsed_time(e1) / it
+
+
+for cin in (128, 16):
+    x = torch.relu(torch.randn(G, 10, 9, cin, device="cuda") * 0.5).bfloat16()
+    w = (torch.randn(128, cin, 3, 3, device="cuda") * (1.0 / (3 * cin ** 0.5))).bfloat16()
+    b = torch.randn(128, device="cuda") * 0.1
+    r = torch.relu(torch.randn(G, 10, 9, 128, device="cuda") * 0.5).bfloat16()
+    wk = w.permute(2, 3, 0, 1).reshape(9, 128, cin).contiguous()
+    y = torch.empty(G, 10, 9, 128, device="cuda", dtype=torch.bfloat16)
+    n = min(G, 512)
     fl = 2.0 * G * 90 * 128 * 9 * cin
-    print("cin=%d G=%d: %.3f ms  %.1f TFLOP/s" % (cin, G, ms, fl / ms / 1e9))
-    # torch/MIOpen reference timing (conv only, no epilogue)
+    for variant in (0, 1):
+        L.xq_conv3x3_set_variant(variant)
+        for use_res in (False, True):
+            y.zero_()
+            _lib.check(L.xq_conv3x3_nhwc_bf16(st, x.data_ptr(), wk.data_ptr(), b.data_ptr(),
+                                              r.data_ptr() if use_res else None, y.data_ptr(), G, cin, 1))
+            torch.cuda.synchronize()
+            ref = F.conv2d(x[:n].permute(0, 3, 1, 2).float(), w.float(), b, padding=1).bfloat16().float()
+            if use_res:
+                ref = ref + r[:n].permute(0, 3, 1, 2).float()
+            ref = torch.relu(ref).permute(0, 2, 3, 1)
+            err = (y[:n].float() - ref).abs().max().item()
+            tail = (y[G - 3:].float() - torch.relu(
+                F.conv2d(x[G - 3:].permute(0, 3, 1, 2).float(), w.float(), b, padding=1).bfloat16().float()
+                + (r[G - 3:].permute(0, 3, 1, 2).float() if use_res else 0)).permute(0, 2, 3, 1)).abs().max().item()
+            print("variant=%d cin=%d res=%d max_abs_err=%.4g tail_err=%.4g" % (variant, cin, use_res, err, tail))
+        ms = timeit(lambda: L.xq_conv3x3_nhwc_bf16(st, x.data_ptr(), wk.data_ptr(), b.data_ptr(), r.data_ptr(),
+                                                    y.data_ptr(), G, cin, 1))
+        print("variant=%d cin=%d G=%d: %.3f ms  %.1f TFLOP/s" % (variant, cin, G, ms, fl / ms / 1e9))
     xt = x.permute(0, 3, 1, 2)
     wt = w.contiguous(memory_format=torch.channels_last)
     bb = b.bfloat16()
-    for _ in range(3):
-        F.conv2d(xt, wt, bb, padding=1)
-    e0.record()
-    for _ in range(it):
-        F.conv2d(xt, wt, bb, padding=1)
-    e1.record()
-    torch.cuda.synchronize()
-    ms2 = e0.elapsed_time(e1) / it
+    ms2 = timeit(lambda: F.conv2d(xt, wt, bb, padding=1))
     print("   torch conv2d+bias: %.3f ms  %.1f TFLOP/s" % (ms2, fl / ms2 / 1e9))
 
-# ---- phase stamps (diagnostic build) ----
-import ctypes as C
+# ---- phase stamps (diagnostic builds) ----
 cin = 128
-x = (torch.randn(G, 10, 9, cin, device="cuda") * 0.5).bfloat16()
+x = torch.relu(torch.randn(G, 10, 9, cin, device="cuda") * 0.5).bfloat16()
 w = (torch.randn(128, cin, 3, 3, device="cuda") * (1.0 / (3 * cin ** 0.5))).bfloat16()
 wk = w.permute(2, 3, 0, 1).reshape(9, 128, cin).contiguous()
 b = torch.randn(128, device="cuda") * 0.1
-r = (torch.randn(G, 10, 9, 128, device="cuda") * 0.5).bfloat16()
+r = torch.relu(torch.randn(G, 10, 9, 128, device="cuda") * 0.5).bfloat16()
 y = torch.empty(G, 10, 9, 128, device="cuda", dtype=torch.bfloat16)
-nwg = (G + 3) // 4
-stamps = torch.zeros(nwg * 16, dtype=torch.int64, device="cuda")
-fn = L.xq_conv3x3_debug_stamps
-fn.argtypes = [C.c_void_p] * 6 + [C.c_int, C.c_int, C.c_void_p]
-for _ in range(2):
-    fn(st, x.data_ptr(), wk.data_ptr(), b.data_ptr(), r.data_ptr(), y.data_ptr(), G, 1, stamps.data_ptr())
-torch.cuda.synchronize()
-s = stamps.cpu().numpy().reshape(nwg, 16)
-import numpy as np
-d = np.diff(s[:, :13], axis=1).astype(np.float64)
-names = ["prologue(load+barrier)"] + ["tap%d" % t for t in range(9)] + ["epi: acc->LDS + barrier", "epi: rows->global"]
-print("phase medians in s_memtime ticks (100 MHz? see total):")
-for i, n in enumerate(names):
-    print("  %-26s median %8.0f  p90 %8.0f" % (n, np.median(d[:, i]), np.percentile(d[:, i], 90)))
-tot = (s[:, 12] - s[:, 0]).astype(np.float64)
-print("  total per WG median %.0f ticks; kernel span %.0f ticks; sum/CU estimate" % (np.median(tot), s[:, 12].max() - s[:, 0].min()))
+for name, nper, slots, last, rt0, rt1, nwg in (("xq_conv3x3_debug_stamps", 16, 13, 12, 13, 14, (G + 3) // 4),
+                                               ("xq_conv3x3_debug_stamps_b", 32, 24, 23, 24, 25, (G + 1) // 2)):
+    stamps = torch.zeros(nwg * nper, dtype=torch.int64, device="cuda")
+    fn = getattr(L, name)
+    fn.argtypes = [C.c_void_p] * 6 + [C.c_int, C.c_int, C.c_void_p]
+    for _ in range(2):
+        fn(st, x.data_ptr(), wk.data_ptr(), b.data_ptr(), r.data_ptr(), y.data_ptr(), G, 1, stamps.data_ptr())
+    torch.cuda.synchronize()
+    s = stamps.cpu().numpy().reshape(nwg, nper)
+    d = np.diff(s[:, :slots], axis=1).astype(np.float64)
+    print(name, "phase medians (shader cycles):", " ".join("%d" % np.median(d[:, i]) for i in range(d.shape[1])))
+    rt = (s[:, rt1] - s[:, rt0]).astype(np.float64)
+    tot = (s[:, last] - s[:, 0]).astype(np.float64)
+    print("   per-WG total median %.0f cycles, clock %.3f GHz, kernel wall %.1f us" % (
+        np.median(tot), np.median(tot / rt * 0.1), (s[:, rt1].max() - s[:, rt0].min()) / 100.0))
