@@ -137,6 +137,8 @@ def lib():
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
+        L.xq_conv3x3_set_variant.argtypes = [C.c_int]          # diagnostic switch, not in the public header
+        L.xq_conv3x3_set_variant.restype = None
         _lib = L
     return _lib
 

@@ -289,6 +289,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_b(const uint16_t *__restrict
     uint8_t *act = lds;
     uint8_t *wbuf = lds + NB * ACT_BYTES;
     uint8_t *zrow = wbuf + 2 * WBUF_BYTES;
+    float *lbias = reinterpret_cast<float *>(zrow + 256);     // 128 floats
 
     auto stamp = [&](int slot) {
         if constexpr (STAMP) {
@@ -324,6 +325,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_b(const uint16_t *__restrict
         }
     };
     if (tid < 16) reinterpret_cast<uint4 *>(zrow)[tid] = make_uint4(0, 0, 0, 0);
+    if (tid >= 64 && tid < 96) reinterpret_cast<f32x4 *>(lbias)[tid - 64] = reinterpret_cast<const f32x4 *>(bias)[tid - 64];
     stage_weights(0, 0);
     if (board_ok) {
         // the two waves of a board each fetch half of it
@@ -356,13 +358,6 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_b(const uint16_t *__restrict
         vmask[nt] = m;
     }
 
-    f32x4 bias_r[2][4];
-#pragma unroll
-    for (int mt = 0; mt < 2; mt++)
-#pragma unroll
-        for (int q = 0; q < 4; q++)
-            bias_r[mt][q] = *reinterpret_cast<const f32x4 *>(bias + hc * 64 + mt * 32 + 8 * q + 4 * h);
-
     f32x16 acc[2][3];
 #pragma unroll
     for (int mt = 0; mt < 2; mt++)
@@ -374,9 +369,23 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_b(const uint16_t *__restrict
     __syncthreads();
     stamp(1);
 
+    // residual rows for the epilogue: requested a few stages before the end of the main loop so
+    // that their HBM latency is covered by MFMA work
+    constexpr int NO = (PIX * 16 + 127) / 128;              // 12 row-chunks per lane
+    uint4 rres[NO];
+    const uint4 *rsrc = (res && board_ok) ? reinterpret_cast<const uint4 *>(res + (size_t)board * PIX * COUT) : nullptr;
+    constexpr int RES_STAGE = NSTAGE > 4 ? NSTAGE - 4 : 0;
+
     for (int st = 0; st < NSTAGE; st++) {
         const int buf = st & 1;
         if (st + 1 < NSTAGE) stage_weights(st + 1, buf ^ 1);
+        if (st == RES_STAGE && rsrc) {
+#pragma unroll
+            for (int j = 0; j < NO; j++) {
+                const int i = (j * 2 + hc) * 64 + lane;
+                rres[j] = (i < PIX * 16) ? rsrc[i] : make_uint4(0, 0, 0, 0);
+            }
+        }
         const int tap = st / SPT, cbase = (st % SPT) * (KSL / 8);
         const int dy = tap / 3 - 1, dx = tap % 3 - 1, off = dy * 9 + dx;
         const uint8_t *wb = wbuf + buf * WBUF_BYTES;
@@ -422,7 +431,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_b(const uint16_t *__restrict
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const int c0 = hc * 64 + mt * 32 + 8 * q + 4 * h;
-            const f32x4 b4 = bias_r[mt][q];
+            const f32x4 b4 = *reinterpret_cast<const f32x4 *>(lbias + c0);
 #pragma unroll
             for (int nt = 0; nt < 3; nt++) {
                 const int p = opix[nt];
@@ -441,16 +450,6 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_b(const uint16_t *__restrict
     if (board_ok) {
         // each wave streams half of its board's rows out (coalesced 16-B chunks), residual + ReLU
         uint4 *dst = reinterpret_cast<uint4 *>(y + (size_t)board * PIX * COUT);
-        const uint4 *rsrc = res ? reinterpret_cast<const uint4 *>(res + (size_t)board * PIX * COUT) : nullptr;
-        constexpr int NO = (PIX * 16 + 127) / 128;          // 12 chunks per lane
-        uint4 rres[NO];
-        if (rsrc) {
-#pragma unroll
-            for (int j = 0; j < NO; j++) {
-                const int i = (j * 2 + hc) * 64 + lane;
-                rres[j] = (i < PIX * 16) ? rsrc[i] : make_uint4(0, 0, 0, 0);
-            }
-        }
 #pragma unroll
         for (int j = 0; j < NO; j++) {
             const int i = (j * 2 + hc) * 64 + lane;
@@ -487,7 +486,7 @@ static int launch_b(hipStream_t s, const void *x, const void *w, const void *bia
                     int n_boards, int relu)
 {
     constexpr int KSL = CIN >= 64 ? 64 : CIN;
-    constexpr int LDS = 2 * PIX * 256 + 2 * COUT * KSL * 2 + 256;
+    constexpr int LDS = 2 * PIX * 256 + 2 * COUT * KSL * 2 + 256 + 512;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv3x3_b<CIN, false>),
@@ -553,7 +552,7 @@ extern "C" int xq_conv3x3_debug_stamps(void *stream, const void *x, const void *
 extern "C" int xq_conv3x3_debug_stamps_b(void *stream, const void *x, const void *w, const void *bias, const void *residual,
                                          void *y, int n_boards, int relu, void *stamps)
 {
-    constexpr int LDS = 2 * PIX * 256 + 2 * COUT * 64 * 2 + 256;
+    constexpr int LDS = 2 * PIX * 256 + 2 * COUT * 64 * 2 + 256 + 512;
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv3x3_b<128, true>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return XQ_E_HIP;
     hipLaunchKernelGGL((k_conv3x3_b<128, true>), dim3((n_boards + 1) / 2), dim3(256), LDS,

@@ -379,6 +379,44 @@ def test_planes_and_network_tolerance(L, golden_dir):
             eng.close()
 
 
+def test_fused_conv_kernel_vs_torch(L):
+    """csrc/xq_conv.hip: y = relu(conv3x3(x, w) + bias [+ residual]) in NHWC bf16 against an fp32
+    torch reference of the same op on the same bf16 inputs.  Tolerance: the kernel rounds conv+bias
+    to bf16 once (<= 1 bf16 ulp = 2^-8 relative) and the residual sum once more -> atol 2^-6 on
+    values of magnitude <= 4.  Both kernel variants, c_in 16 and 128, odd board counts (tail
+    workgroup), with / without residual and ReLU."""
+    import torch
+    import torch.nn.functional as F
+    from chinesechessai_amd import _lib
+    torch.manual_seed(1)
+    st = torch.cuda.current_stream().cuda_stream
+    for variant in (1, 0):
+        L.xq_conv3x3_set_variant(variant)
+        for cin, G in ((128, 37), (16, 37), (128, 1), (128, 8)):
+            x = (torch.randn(G, 10, 9, cin, device="cuda") * 0.5).bfloat16()
+            w = (torch.randn(128, cin, 3, 3, device="cuda") / (3 * cin ** 0.5)).bfloat16()
+            b = torch.randn(128, device="cuda") * 0.1
+            r = (torch.randn(G, 10, 9, 128, device="cuda") * 0.5).bfloat16()
+            wk = w.permute(2, 3, 0, 1).reshape(9, 128, cin).contiguous()
+            for use_res in (False, True):
+                for relu in (1, 0):
+                    y = torch.full((G + 1, 10, 9, 128), 7.0, device="cuda", dtype=torch.bfloat16)
+                    _lib.check(L.xq_conv3x3_nhwc_bf16(st, x.data_ptr(), wk.data_ptr(), b.data_ptr(),
+                                                      r.data_ptr() if use_res else None, y.data_ptr(), G, cin, relu))
+                    torch.cuda.synchronize()
+                    ref = F.conv2d(x.permute(0, 3, 1, 2).float(), w.float(), b, padding=1)
+                    if use_res:
+                        ref = ref + r.permute(0, 3, 1, 2).float()
+                    if relu:
+                        ref = torch.relu(ref)
+                    ref = ref.permute(0, 2, 3, 1)
+                    assert (y[:G].float() - ref).abs().max().item() <= 2 ** -6 + 2 ** -7 * ref.abs().max().item()
+                    assert (y[G] == 7.0).all(), "wrote past the last board"
+    L.xq_conv3x3_set_variant(1)
+    assert L.xq_conv3x3_nhwc_bf16(st, None, None, None, None, None, 4, 128, 1) == -1
+    assert L.xq_conv3x3_nhwc_bf16(st, x.data_ptr(), wk.data_ptr(), b.data_ptr(), None, y.data_ptr(), 4, 64, 1) == -1
+
+
 def test_real_network_game_runs_and_invariants(L):
     """Statistical parity with the real net is bounded by H2: here the invariants
     every reference game satisfies — visit totals S-8 per ply (A10), pi sums to 1, z from the
