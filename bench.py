@@ -133,6 +133,7 @@ def main():
     ap.add_argument("--profile-plies", type=int, default=0,
                     help="profiling aid only: stop every step after this many plies (the JSON line is then NOT a benchmark)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--net-chunk", type=int, default=0, help="rows per network launch (0 = all games at once)")
     args = ap.parse_args()
 
     import torch
@@ -157,7 +158,7 @@ def main():
     torch.manual_seed(0)                                   # same random-init weights on every rank
     net = ChessNet(num_blocks=args.blocks).eval().cuda()
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-    ev = TorchNetEvaluator(net, dtype=dtype)
+    ev = TorchNetEvaluator(net, dtype=dtype, chunk=args.net_chunk or None)
     stream = torch.cuda.current_stream().cuda_stream
     records = torch.zeros(G * _lib.MAX_PLIES * xd.RECORD_BYTES, dtype=torch.uint8, device="cuda")
 

@@ -268,7 +268,8 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3(const uint16_t *__restrict__
 //   weights streamed in K-slices of KSL input channels: [128 cout][KSL] double-buffered (32 KB)
 //   LDS per workgroup: 2 x 23,040 (boards / output staging) + 32,768 + 256 = 79,104 B
 // ------------------------------------------------------------------------------------------
-template <int CIN, bool STAMP = false>
+// ABLATE (diagnostic builds only, results are wrong): 1 = no stage barriers / weight DMA in the main loop
+template <int CIN, bool STAMP = false, int ABLATE = 0>
 __global__ __launch_bounds__(256, 2) void k_conv3x3_b(const uint16_t *__restrict__ x, const uint16_t *__restrict__ w,
                                                       const float *__restrict__ bias, const uint16_t *__restrict__ res,
                                                       uint16_t *__restrict__ y, int G, int relu,
@@ -376,56 +377,74 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_b(const uint16_t *__restrict
     const uint4 *rsrc = (res && board_ok) ? reinterpret_cast<const uint4 *>(res + (size_t)board * PIX * COUT) : nullptr;
     constexpr int RES_STAGE = NSTAGE > 4 ? NSTAGE - 4 : 0;
 
-    for (int st = 0; st < NSTAGE; st++) {
-        const int buf = st & 1;
-        if (st + 1 < NSTAGE) stage_weights(st + 1, buf ^ 1);
-        if (st == RES_STAGE && rsrc) {
+    // per-lane byte offsets of the weight fragments inside a stage buffer: fixed for the whole kernel
+    int aoff[2][KSTEPS];
 #pragma unroll
-            for (int j = 0; j < NO; j++) {
-                const int i = (j * 2 + hc) * 64 + lane;
-                rres[j] = (i < PIX * 16) ? rsrc[i] : make_uint4(0, 0, 0, 0);
-            }
+    for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+        for (int kk = 0; kk < KSTEPS; kk++) {
+            const int row = hc * 64 + mt * 32 + r32, cw = kk * 2 + h;
+            aoff[mt][kk] = row * WROWB + ((cw ^ wswz(row)) * 16);
         }
-        const int tap = st / SPT, cbase = (st % SPT) * (KSL / 8);
+    const int act_off = (int)(my_act - lds), zrow_off = (int)(zrow - lds), wbuf_off = (int)(wbuf - lds);
+
+    for (int tap = 0; tap < 9; tap++) {
         const int dy = tap / 3 - 1, dx = tap % 3 - 1, off = dy * 9 + dx;
-        const uint8_t *wb = wbuf + buf * WBUF_BYTES;
-        const uint8_t *brow[3];
-        int bswz[3];
+        // row address with the swizzle folded in: chunk c of the row lives at a0 ^ (c << 4)
+        // (rows are ROWB-aligned, so the XOR only touches the chunk bits); padding -> zero row
+        int a0[3];
 #pragma unroll
         for (int nt = 0; nt < 3; nt++) {
             const bool ok = (vmask[nt] >> tap) & 1u;
             const int sp = opix[nt] + off;
-            brow[nt] = ok ? my_act + sp * ROWB : zrow;
-            bswz[nt] = ok ? aswz(sp) : 0;
+            a0[nt] = ok ? act_off + sp * ROWB + ((aswz(sp) ^ h) << 4) : zrow_off + (h << 4);
         }
-        auto load_frags = [&](int kk, bf16x8 (&bf)[3], bf16x8 (&af)[2]) {
-            const int cw = kk * 2 + h, ca = cbase + cw;
 #pragma unroll
-            for (int nt = 0; nt < 3; nt++)
-                bf[nt] = *reinterpret_cast<const bf16x8 *>(brow[nt] + ((ca ^ bswz[nt]) * 16));
+        for (int sl = 0; sl < SPT; sl++) {
+            const int st = tap * SPT + sl;
+            const int buf = (SPT == 2) ? sl : (st & 1);            // compile-time when SPT == 2
+            // next stage's weight slice by LDS-DMA into the other buffer.  (Register staging — plain
+            // dwordx4 loads + ds_write_b128 at the end of the stage — was measured 1.55x SLOWER here:
+            // the wave stalls on the load latency before the barrier; tools/bench_conv.py.)
+            if (ABLATE != 1 && ABLATE != 2 && st + 1 < NSTAGE) stage_weights(st + 1, buf ^ 1);
+            if (st == RES_STAGE && rsrc) {
 #pragma unroll
-            for (int mt = 0; mt < 2; mt++) {
-                const int row = hc * 64 + mt * 32 + r32;
-                af[mt] = *reinterpret_cast<const bf16x8 *>(wb + row * WROWB + ((cw ^ wswz(row)) * 16));
+                for (int j = 0; j < NO; j++) {
+                    const int i = (j * 2 + hc) * 64 + lane;
+                    rres[j] = (i < PIX * 16) ? rsrc[i] : make_uint4(0, 0, 0, 0);
+                }
             }
-        };
-        bf16x8 bfr[2][3], afr[2][2];
-        load_frags(0, bfr[0], afr[0]);
-#pragma unroll
-        for (int kk = 0; kk < KSTEPS; kk++) {
-            const int cur = kk & 1;
-            if (kk + 1 < KSTEPS) load_frags(kk + 1, bfr[cur ^ 1], afr[cur ^ 1]);
-#pragma unroll
-            for (int mt = 0; mt < 2; mt++)
+            const int wb_off = wbuf_off + buf * WBUF_BYTES;
+            auto load_frags = [&](int kk, bf16x8 (&bf)[3], bf16x8 (&af)[2]) {
+                const int cconst = (sl * (KSL / 8) + kk * 2) << 4;      // compile-time
 #pragma unroll
                 for (int nt = 0; nt < 3; nt++)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[cur][mt], bfr[cur][nt], acc[mt][nt], 0, 0, 0);
+                    bf[nt] = *reinterpret_cast<const bf16x8 *>(lds + (a0[nt] ^ cconst));
+#pragma unroll
+                for (int mt = 0; mt < 2; mt++)
+                    af[mt] = *reinterpret_cast<const bf16x8 *>(lds + wb_off + aoff[mt][kk]);
+            };
+            bf16x8 bfr[2][3], afr[2][2];
+            load_frags(0, bfr[0], afr[0]);
+#pragma unroll
+            for (int kk = 0; kk < KSTEPS; kk++) {
+                const int cur = kk & 1;
+                if (kk + 1 < KSTEPS) load_frags(kk + 1, bfr[cur ^ 1], afr[cur ^ 1]);
+#pragma unroll
+                for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+                    for (int nt = 0; nt < 3; nt++)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[cur][mt], bfr[cur][nt], acc[mt][nt], 0, 0, 0);
+            }
+            if (ABLATE != 1 && ABLATE != 3) __syncthreads();
+            if constexpr (STAMP) { if (st < 18) stamp(2 + st); }
         }
-        __syncthreads();
-        if constexpr (STAMP) { if (st < 18) stamp(2 + st); }
     }
 
+    stamp(20);
     // ---- epilogue: +bias -> bf16 -> the board's region [pixel][128 cout] (both channel halves) ----
+    const bool early_relu = relu && !res;       // without a residual the ReLU is applied here and
+                                                // the way out is a plain copy
 #pragma unroll
     for (int mt = 0; mt < 2; mt++) {
 #pragma unroll
@@ -436,8 +455,12 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_b(const uint16_t *__restrict
             for (int nt = 0; nt < 3; nt++) {
                 const int p = opix[nt];
                 if (p < PIX) {
-                    const float v0 = acc[mt][nt][4 * q + 0] + b4[0], v1 = acc[mt][nt][4 * q + 1] + b4[1];
-                    const float v2 = acc[mt][nt][4 * q + 2] + b4[2], v3 = acc[mt][nt][4 * q + 3] + b4[3];
+                    float v0 = acc[mt][nt][4 * q + 0] + b4[0], v1 = acc[mt][nt][4 * q + 1] + b4[1];
+                    float v2 = acc[mt][nt][4 * q + 2] + b4[2], v3 = acc[mt][nt][4 * q + 3] + b4[3];
+                    if (early_relu) {
+                        v0 = v0 > 0.f ? v0 : 0.f; v1 = v1 > 0.f ? v1 : 0.f;
+                        v2 = v2 > 0.f ? v2 : 0.f; v3 = v3 > 0.f ? v3 : 0.f;
+                    }
                     uint2 pk = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
                     const int chunk = (c0 * 2) / 16, inner = (c0 * 2) % 16;
                     *reinterpret_cast<uint2 *>(my_act + p * 256 + ((chunk ^ (p & 15)) * 16) + inner) = pk;
@@ -445,8 +468,9 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_b(const uint16_t *__restrict
             }
         }
     }
-    __syncthreads();
     stamp(21);
+    __syncthreads();
+    stamp(22);
     if (board_ok) {
         // each wave streams half of its board's rows out (coalesced 16-B chunks), residual + ReLU
         uint4 *dst = reinterpret_cast<uint4 *>(y + (size_t)board * PIX * COUT);
@@ -459,7 +483,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_b(const uint16_t *__restrict
                 uint32_t wv[4] = { v.x, v.y, v.z, v.w };
                 uint32_t rv[4] = { 0, 0, 0, 0 };
                 if (rsrc) { rv[0] = rres[j].x; rv[1] = rres[j].y; rv[2] = rres[j].z; rv[3] = rres[j].w; }
-                if (rsrc || relu) {
+                if (rsrc) {
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
                         float lo = bf16_lo(wv[k]) + bf16_lo(rv[k]), hi = bf16_hi(wv[k]) + bf16_hi(rv[k]);
@@ -549,6 +573,36 @@ extern "C" int xq_conv3x3_debug_stamps(void *stream, const void *x, const void *
 }
 
 // diagnostic only: phase stamps of variant B (c_in = 128): 32 u64 per workgroup
+template <int AB>
+static int launch_dbg_b(void *stream, const void *x, const void *w, const void *bias, const void *residual, void *y,
+                        int n_boards, int relu, void *stamps)
+{
+    constexpr int LDS = 2 * PIX * 256 + 2 * COUT * 64 * 2 + 256 + 512;
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv3x3_b<128, true, AB>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return XQ_E_HIP;
+    hipLaunchKernelGGL((k_conv3x3_b<128, true, AB>), dim3((n_boards + 1) / 2), dim3(256), LDS,
+                       reinterpret_cast<hipStream_t>(stream), (const uint16_t *)x, (const uint16_t *)w, (const float *)bias,
+                       (const uint16_t *)residual, (uint16_t *)y, n_boards, relu, (unsigned long long *)stamps);
+    return hipGetLastError() == hipSuccess ? 0 : XQ_E_HIP;
+}
+// 2 = barriers but no weight DMA; 3 = weight DMA but no barriers (both give wrong results)
+extern "C" int xq_conv3x3_debug_stamps_b_nodma(void *s, const void *x, const void *w, const void *b, const void *r, void *y,
+                                               int n, int relu, void *st) { return launch_dbg_b<2>(s, x, w, b, r, y, n, relu, st); }
+extern "C" int xq_conv3x3_debug_stamps_b_nobar(void *s, const void *x, const void *w, const void *b, const void *r, void *y,
+                                               int n, int relu, void *st) { return launch_dbg_b<3>(s, x, w, b, r, y, n, relu, st); }
+
+extern "C" int xq_conv3x3_debug_stamps_b_nosync(void *stream, const void *x, const void *w, const void *bias,
+                                                const void *residual, void *y, int n_boards, int relu, void *stamps)
+{
+    constexpr int LDS = 2 * PIX * 256 + 2 * COUT * 64 * 2 + 256 + 512;
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv3x3_b<128, true, 1>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return XQ_E_HIP;
+    hipLaunchKernelGGL((k_conv3x3_b<128, true, 1>), dim3((n_boards + 1) / 2), dim3(256), LDS,
+                       reinterpret_cast<hipStream_t>(stream), (const uint16_t *)x, (const uint16_t *)w, (const float *)bias,
+                       (const uint16_t *)residual, (uint16_t *)y, n_boards, relu, (unsigned long long *)stamps);
+    return hipGetLastError() == hipSuccess ? 0 : XQ_E_HIP;
+}
+
 extern "C" int xq_conv3x3_debug_stamps_b(void *stream, const void *x, const void *w, const void *bias, const void *residual,
                                          void *y, int n_boards, int relu, void *stamps)
 {

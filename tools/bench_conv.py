@@ -70,7 +70,10 @@ b = torch.randn(128, device="cuda") * 0.1
 r = torch.relu(torch.randn(G, 10, 9, 128, device="cuda") * 0.5).bfloat16()
 y = torch.empty(G, 10, 9, 128, device="cuda", dtype=torch.bfloat16)
 for name, nper, slots, last, rt0, rt1, nwg in (("xq_conv3x3_debug_stamps", 16, 13, 12, 13, 14, (G + 3) // 4),
-                                               ("xq_conv3x3_debug_stamps_b", 32, 24, 23, 24, 25, (G + 1) // 2)):
+                                               ("xq_conv3x3_debug_stamps_b", 32, 24, 23, 24, 25, (G + 1) // 2),
+                                               ("xq_conv3x3_debug_stamps_b_nosync", 32, 24, 23, 24, 25, (G + 1) // 2),
+                                               ("xq_conv3x3_debug_stamps_b_nodma", 32, 24, 23, 24, 25, (G + 1) // 2),
+                                               ("xq_conv3x3_debug_stamps_b_nobar", 32, 24, 23, 24, 25, (G + 1) // 2)):
     stamps = torch.zeros(nwg * nper, dtype=torch.int64, device="cuda")
     fn = getattr(L, name)
     fn.argtypes = [C.c_void_p] * 6 + [C.c_int, C.c_int, C.c_void_p]
@@ -80,6 +83,10 @@ for name, nper, slots, last, rt0, rt1, nwg in (("xq_conv3x3_debug_stamps", 16, 1
     s = stamps.cpu().numpy().reshape(nwg, nper)
     d = np.diff(s[:, :slots], axis=1).astype(np.float64)
     print(name, "phase medians (shader cycles):", " ".join("%d" % np.median(d[:, i]) for i in range(d.shape[1])))
+    if nper == 32:
+        print("   B: prologue %d | stages sum %d | acc->LDS %d | barrier %d | rows->global %d" % (
+            np.median(d[:, 0]), np.median(d[:, 1:19].sum(axis=1)), np.median(s[:, 21] - s[:, 20]),
+            np.median(s[:, 22] - s[:, 21]), np.median(s[:, 23] - s[:, 22])))
     rt = (s[:, rt1] - s[:, rt0]).astype(np.float64)
     tot = (s[:, last] - s[:, 0]).astype(np.float64)
     print("   per-WG total median %.0f cycles, clock %.3f GHz, kernel wall %.1f us" % (
