@@ -12,9 +12,10 @@ BASELINE.json configs[2], the configuration the metric is quoted on (S = 50):
 positions, per-game seeds base+g.  Games shard across GPUs with no data-path collective
 (weak scaling: G per GPU fixed).
 
-Prints ONE JSON line (rank 0).  `roofline` = the dominant cost of the step (the network forward,
-MFMA-bound); `roofline_tree` = the dominant hand-written kernel (k_search_round, HBM-bound
-integer work); both measured live with events on the stream the kernels run on.
+Prints ONE JSON line (rank 0).  `roofline` = the dominant kernel of the step, the hand-written
+fused conv k_conv3x3_b<128> (MFMA-bound, ~83 % of GPU time); `roofline_net` = the whole network
+forward; `roofline_tree` = the tree/rules kernel k_search_round (HBM-bound integer work); all
+measured live with events on the stream the kernels run on.
 `cpu_baseline` = the CPU oracle ("port" of the reference algorithm, net on CPU torch) timed on the
 host cores on a bounded sample.
 """
@@ -97,7 +98,7 @@ def _cpu_worker(args):
     return time.time() - t0, g.n_plies, rc
 
 
-def cpu_baseline(blocks, sims, workers=4, plies=16, max_cores=16):
+def cpu_baseline(blocks, sims, workers=4, plies=70, max_cores=16):
     """4 worker processes x 1 game each, mirroring NUM_WORKERS=4 (config.py:48, self_play.py:404),
     intra-op threads pinned to cores/4 (the reference's unpinned default oversubscribes,
     BASELINE.md §2).  Bounded sample: the first `plies` plies of each game, scaled to games/s by
@@ -134,6 +135,7 @@ def main():
                     help="profiling aid only: stop every step after this many plies (the JSON line is then NOT a benchmark)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--net-chunk", type=int, default=0, help="rows per network launch (0 = all games at once)")
+    ap.add_argument("--conv-variant", type=int, default=0, help="diagnostic: 1 = 2 boards/WG, 2 = 4 boards/WG (0 = library default)")
     args = ap.parse_args()
 
     import torch
@@ -143,6 +145,8 @@ def main():
     from chinesechessai_amd.engine import SelfPlayEngine, TorchNetEvaluator
     from chinesechessai_amd.neural_network import ChessNet
 
+    if args.conv_variant:
+        _lib.lib().xq_conv3x3_set_variant(args.conv_variant)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -164,6 +168,7 @@ def main():
 
     # time the network forward with events on its own (= the engine's) stream
     fw_events = []
+    tower_events = []
     orig_eval = ev.evaluate
 
     def timed_eval(engine):
@@ -176,6 +181,7 @@ def main():
 
     def step(eng, base_seed, timed):
         ev.evaluate = timed_eval if timed else orig_eval
+        ev.inet.tower_events = tower_events if timed else None
         seeds = xd.game_seeds(base_seed, G * world, rank, world)
         eng.play(ev, seeds, read=False)
         eng.pack_samples(records.data_ptr())
@@ -219,6 +225,11 @@ def main():
         net_tflops = (fl * rows * n_fw) / (fw_ms * 1e-3) / 1e12 if fw_ms > 0 else 0.0
         bpd = tree_bytes_per_descent()
         tree_gbs = (bpd * G * prof["search_launches"]) / (prof["search_ms"] * 1e-3) / 1e9 if prof["search_ms"] > 0 else 0.0
+        # dominant kernel: the hand-written fused conv (2 per residual block, 128 -> 128 channels)
+        n_conv = 2 * args.blocks * len(tower_events)
+        conv_ms = sum(a.elapsed_time(b) for a, b in tower_events)
+        conv_fl = 2.0 * G * 90 * 128 * 9 * 128
+        conv_tflops = conv_fl * n_conv / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
         out = {
             "metric": "self-play games/sec @ 50 MCTS sims" if S == 50 else "self-play games/sec @ %d MCTS sims" % S,
             "value": games / dt, "unit": "games/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -229,11 +240,17 @@ def main():
                                    "random-init weights, start positions, seeds base+g" % (G, S, args.blocks, args.dtype),
                        "games_per_gpu": G, "sims": S, "blocks": args.blocks, "max_moves": 70,
                        "parallelism": "games sharded x%d, all-gather of samples at step end" % world},
-            "roofline": {"bound": "mfma", "achieved": net_tflops, "peak": MFMA_PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": net_tflops / MFMA_PEAK_BF16_TFLOPS, "traffic": None,
-                         "kernel": "network forward (PyTorch-ROCm, %d launches of %d rows, %.3f ms avg)" % (
-                             n_fw, rows, fw_ms / max(n_fw, 1)),
-                         "flops_per_launch": fl * rows},
+            "roofline": {"bound": "mfma", "achieved": conv_tflops, "peak": MFMA_PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": conv_tflops / MFMA_PEAK_BF16_TFLOPS, "traffic": None,
+                         "kernel": "k_conv3x3_b<128> (hand-written fused conv3x3+bias+residual+ReLU; %d launches of %d "
+                                   "boards, %.4f ms avg; %.0f%% of the step)" % (
+                                       n_conv, G, conv_ms / max(n_conv, 1), 100.0 * conv_ms / (dt * 1e3)),
+                         "flops_per_launch": conv_fl},
+            "roofline_net": {"bound": "mfma", "achieved": net_tflops, "peak": MFMA_PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                             "frac": net_tflops / MFMA_PEAK_BF16_TFLOPS, "traffic": None,
+                             "kernel": "whole network forward (%d launches of %d rows, %.3f ms avg)" % (
+                                 n_fw, rows, fw_ms / max(n_fw, 1)),
+                             "flops_per_launch": fl * rows},
             "roofline_tree": {"bound": "hbm", "achieved": tree_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": tree_gbs / HBM_PEAK_GBS, "traffic": tree_traffic(G, S, args.blocks),
                               "kernel": "k_search_round (%d launches, %.3f ms avg)" % (

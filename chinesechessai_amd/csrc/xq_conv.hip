@@ -31,7 +31,6 @@ namespace {
 
 constexpr int PIX = 90;
 constexpr int COUT = 128;
-constexpr int BOARDS_PER_WG = 4;
 
 __device__ __forceinline__ uint32_t pack_bf16x2(float a, float b)
 {
@@ -53,214 +52,6 @@ __device__ __forceinline__ void dma16(const void *gsrc, void *lds_wave_base)
                                      (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
 }
 
-// STAMP = diagnostic build only (tools/bench_conv.py): wave 0 of each workgroup writes s_memtime
-// phase stamps to a buffer of their own; the production instantiation executes no stamp.
-template <int CIN, bool STAMP = false>
-__global__ __launch_bounds__(256, 1) void k_conv3x3(const uint16_t *__restrict__ x, const uint16_t *__restrict__ w,
-                                                    const float *__restrict__ bias, const uint16_t *__restrict__ res,
-                                                    uint16_t *__restrict__ y, int G, int relu,
-                                                    unsigned long long *stamps = nullptr)
-{
-    auto stamp = [&](int slot) {
-        if constexpr (STAMP) {
-            unsigned long long t = __builtin_amdgcn_s_memtime();
-            if (threadIdx.x == 0) stamps[(size_t)blockIdx.x * 16 + slot] = t;
-            if (slot == 0 || slot == 12) {      // 100 MHz wall clock at both ends -> in-kernel shader clock
-                unsigned long long rt = __builtin_amdgcn_s_memrealtime();
-                if (threadIdx.x == 0) stamps[(size_t)blockIdx.x * 16 + (slot == 0 ? 13 : 14)] = rt;
-            }
-        }
-    };
-    stamp(0);
-    constexpr int ROWB = CIN * 2;                 // bytes per pixel row / per cout row of a tap slice
-    constexpr int NCH = CIN / 8;                  // 16-byte chunks per row
-    constexpr int SWZ = NCH >= 16 ? 15 : NCH - 1; // chunk swizzle mask
-    constexpr int KSTEPS = CIN / 16;              // k-steps of 16 per tap
-    constexpr int ACT_BYTES = PIX * 256;          // per-board region (also holds the 128-ch output)
-    constexpr int WBUF_BYTES = COUT * ROWB;
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    uint8_t *act = lds;                                            // [4][ACT_BYTES]
-    uint8_t *wbuf = lds + BOARDS_PER_WG * ACT_BYTES;               // [2][WBUF_BYTES]
-    uint8_t *zrow = wbuf + 2 * WBUF_BYTES;                         // 256 zero bytes: the padding "pixel"
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int board = blockIdx.x * BOARDS_PER_WG + wave;
-    const bool board_ok = board < G;
-    uint8_t *my_act = act + wave * ACT_BYTES;
-
-    // ---- stage tap 0 weights and this wave's board by LDS-DMA (issued back to back, one wait) ----
-    constexpr int WCHUNKS_PER_WAVE = COUT * NCH / 4;        // each wave stages a quarter of a tap slice
-    constexpr int WINSTR = WCHUNKS_PER_WAVE / 64;           // 8 (CIN 128) or 1 (CIN 16)
-    static_assert(WINSTR * 64 == WCHUNKS_PER_WAVE, "tap slice must tile over 4 waves x 64 lanes");
-    auto stage_weights = [&](int tap, int buf) {
-        const uint8_t *src = reinterpret_cast<const uint8_t *>(w) + (size_t)tap * COUT * ROWB;
-#pragma unroll
-        for (int j = 0; j < WINSTR; j++) {
-            const int q0 = (wave * WINSTR + j) * 64;        // first LDS chunk of this instruction
-            const int q = q0 + lane, row = q / NCH, cp = q % NCH;
-            dma16(src + row * ROWB + ((cp ^ (row & SWZ)) * 16), wbuf + buf * WBUF_BYTES + q0 * 16);
-        }
-    };
-    if (tid < 16) reinterpret_cast<uint4 *>(zrow)[tid] = make_uint4(0, 0, 0, 0);
-    stage_weights(0, 0);
-    if (board_ok) {
-        const uint8_t *src = reinterpret_cast<const uint8_t *>(x) + (size_t)board * PIX * ROWB;
-        constexpr int NI = (PIX * NCH + 63) / 64;
-#pragma unroll
-        for (int j = 0; j < NI; j++) {
-            const int q = j * 64 + lane, p = q / NCH, cp = q % NCH;
-            if (q < PIX * NCH) dma16(src + p * ROWB + ((cp ^ (p & SWZ)) * 16), my_act + j * 1024);
-        }
-    }
-
-    // per-lane geometry of the 3 pixel tiles
-    const int r32 = lane & 31, h = lane >> 5;
-    int opix[3];
-    uint32_t vmask[3];                // bit t = tap t reads a real pixel (zero padding otherwise)
-#pragma unroll
-    for (int nt = 0; nt < 3; nt++) {
-        const int o = nt * 32 + r32;
-        opix[nt] = o;
-        uint32_t m = 0;
-        if (o < PIX) {
-            const int yy = o / 9, xx = o % 9;
-#pragma unroll
-            for (int t = 0; t < 9; t++) {
-                const int dy = t / 3 - 1, dx = t % 3 - 1;
-                if (yy + dy >= 0 && yy + dy < 10 && xx + dx >= 0 && xx + dx < 9) m |= 1u << t;
-            }
-        }
-        vmask[nt] = m;
-    }
-
-    // bias for the 64 output channels this lane owns (registers 4q..4q+3 of channel tile mt):
-    // fetched now, all 16 loads in flight, consumed after the main loop
-    f32x4 bias_r[4][4];
-#pragma unroll
-    for (int mt = 0; mt < 4; mt++)
-#pragma unroll
-        for (int q = 0; q < 4; q++)
-            bias_r[mt][q] = *reinterpret_cast<const f32x4 *>(bias + mt * 32 + 8 * q + 4 * h);
-
-    f32x16 acc[4][3];
-#pragma unroll
-    for (int mt = 0; mt < 4; mt++)
-#pragma unroll
-        for (int nt = 0; nt < 3; nt++)
-#pragma unroll
-            for (int i = 0; i < 16; i++) acc[mt][nt][i] = 0.f;
-
-    __syncthreads();
-    stamp(1);
-
-    for (int tap = 0; tap < 9; tap++) {
-        const int buf = tap & 1;
-        // prefetch the next tap's weight slice straight into the other LDS buffer (its last
-        // readers finished before the barrier that ended the previous tap)
-        if (tap + 1 < 9) stage_weights(tap + 1, buf ^ 1);
-        const int dy = tap / 3 - 1, dx = tap % 3 - 1, off = dy * 9 + dx;
-        const uint8_t *wb = wbuf + buf * WBUF_BYTES;
-        // per-lane row pointers of this tap: a real pixel row, or the zero row for padding
-        // (no per-fragment select, no dependency between the LDS read and the MFMA)
-        const uint8_t *brow[3];
-        int bswz[3];
-#pragma unroll
-        for (int nt = 0; nt < 3; nt++) {
-            const bool ok = (vmask[nt] >> tap) & 1u;
-            const int sp = opix[nt] + off;
-            brow[nt] = ok ? my_act + sp * ROWB : zrow;
-            bswz[nt] = ok ? (sp & SWZ) : 0;
-        }
-        auto load_frags = [&](int kk, bf16x8 (&bf)[3], bf16x8 (&af)[4]) {
-            const int c = kk * 2 + h;
-#pragma unroll
-            for (int nt = 0; nt < 3; nt++)
-                bf[nt] = *reinterpret_cast<const bf16x8 *>(brow[nt] + ((c ^ bswz[nt]) * 16));
-#pragma unroll
-            for (int mt = 0; mt < 4; mt++) {
-                const int row = mt * 32 + r32;
-                af[mt] = *reinterpret_cast<const bf16x8 *>(wb + row * ROWB + ((c ^ (row & SWZ)) * 16));
-            }
-        };
-        // software pipeline: fragments of k-step kk+1 are in flight while the 12 MFMAs of kk run
-        bf16x8 bfr[2][3], afr[2][4];
-        load_frags(0, bfr[0], afr[0]);
-#pragma unroll
-        for (int kk = 0; kk < KSTEPS; kk++) {
-            const int cur = kk & 1;
-            if (kk + 1 < KSTEPS) load_frags(kk + 1, bfr[cur ^ 1], afr[cur ^ 1]);
-#pragma unroll
-            for (int mt = 0; mt < 4; mt++)
-#pragma unroll
-                for (int nt = 0; nt < 3; nt++)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[cur][mt], bfr[cur][nt], acc[mt][nt], 0, 0, 0);
-        }
-        __syncthreads();
-        stamp(2 + tap);
-    }
-
-    // ---- epilogue: D[row = cout][col = pixel]; lane holds pixel r32 of each tile and couts
-    //      mt*32 + 8q + 4h + (0..3) in registers 4q..4q+3
-#pragma unroll
-    for (int mt = 0; mt < 4; mt++) {
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int c0 = mt * 32 + 8 * q + 4 * h;
-            const f32x4 b4 = bias_r[mt][q];
-#pragma unroll
-            for (int nt = 0; nt < 3; nt++) {
-                const int p = opix[nt];
-                if (p < PIX) {
-                    const float v0 = acc[mt][nt][4 * q + 0] + b4[0], v1 = acc[mt][nt][4 * q + 1] + b4[1];
-                    const float v2 = acc[mt][nt][4 * q + 2] + b4[2], v3 = acc[mt][nt][4 * q + 3] + b4[3];
-                    uint2 pk = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
-                    const int chunk = (c0 * 2) / 16, inner = (c0 * 2) % 16;
-                    *reinterpret_cast<uint2 *>(my_act + p * 256 + ((chunk ^ (p & 15)) * 16) + inner) = pk;
-                }
-            }
-        }
-    }
-    // residual rows are fetched up front (all loads in flight together: one wave per SIMD has
-    // nothing else to hide a dependent load behind)
-    constexpr int NO = (PIX * 16 + 63) / 64;                 // 23 row-chunks per lane
-    uint4 rres[NO];
-    const uint4 *rsrc = (res && board_ok) ? reinterpret_cast<const uint4 *>(res + (size_t)board * PIX * COUT) : nullptr;
-    if (rsrc) {
-#pragma unroll
-        for (int j = 0; j < NO; j++) {
-            const int i = j * 64 + lane;
-            rres[j] = (i < PIX * 16) ? rsrc[i] : make_uint4(0, 0, 0, 0);
-        }
-    }
-    __syncthreads();
-    stamp(11);
-    if (board_ok) {
-        uint4 *dst = reinterpret_cast<uint4 *>(y + (size_t)board * PIX * COUT);
-#pragma unroll
-        for (int j = 0; j < NO; j++) {
-            const int i = j * 64 + lane;
-            if (i < PIX * 16) {
-                const int p = i >> 4, c = i & 15;
-                uint4 v = *reinterpret_cast<const uint4 *>(my_act + p * 256 + ((c ^ (p & 15)) * 16));
-                uint32_t wv[4] = { v.x, v.y, v.z, v.w };
-                uint32_t rv[4] = { 0, 0, 0, 0 };
-                if (rsrc) { rv[0] = rres[j].x; rv[1] = rres[j].y; rv[2] = rres[j].z; rv[3] = rres[j].w; }
-                if (rsrc || relu) {
-#pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        float lo = bf16_lo(wv[k]) + bf16_lo(rv[k]), hi = bf16_hi(wv[k]) + bf16_hi(rv[k]);
-                        if (relu) { lo = lo > 0.f ? lo : 0.f; hi = hi > 0.f ? hi : 0.f; }
-                        wv[k] = pack_bf16x2(lo, hi);
-                    }
-                }
-                dst[i] = make_uint4(wv[0], wv[1], wv[2], wv[3]);
-            }
-        }
-    }
-    stamp(12);
-}
-
-
 // ------------------------------------------------------------------------------------------
 // Variant B: 2 boards per workgroup, 2 workgroups per CU (8 waves, two per SIMD) so that one
 // workgroup's load / store phases and barriers hide behind the other's MFMA work.
@@ -269,16 +60,20 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3(const uint16_t *__restrict__
 //   LDS per workgroup: 2 x 23,040 (boards / output staging) + 32,768 + 256 = 79,104 B
 // ------------------------------------------------------------------------------------------
 // ABLATE (diagnostic builds only, results are wrong): 1 = no stage barriers / weight DMA in the main loop
-template <int CIN, bool STAMP = false, int ABLATE = 0>
-__global__ __launch_bounds__(256, 2) void k_conv3x3_b(const uint16_t *__restrict__ x, const uint16_t *__restrict__ w,
+// NB = boards per workgroup (2 waves per board), KSLP = input channels per weight stage.
+//   variant B: NB 2, KSLP 64  -> 256 threads, 79.6 KB LDS, 2 workgroups per CU, 18 stages
+//   variant C: NB 4, KSLP 128 -> 512 threads, 158.5 KB LDS, 1 workgroup per CU, 9 stages (half the
+//              weight re-streaming and half the barriers / DMA pieces of B)
+template <int CIN, int NB, int KSLP, bool STAMP = false, int ABLATE = 0>
+__global__ __launch_bounds__(NB * 128, 2) void k_conv3x3_b(const uint16_t *__restrict__ x, const uint16_t *__restrict__ w,
                                                       const float *__restrict__ bias, const uint16_t *__restrict__ res,
                                                       uint16_t *__restrict__ y, int G, int relu,
                                                       unsigned long long *stamps = nullptr)
 {
-    constexpr int NB = 2;
+    constexpr int NT = NB * 128;                         // threads per workgroup
     constexpr int ROWB = CIN * 2, NCH = CIN / 8;
     constexpr int ARP = 256 / ROWB >= 1 ? (ROWB >= 256 ? 1 : 256 / ROWB) : 1;     // act rows per 256 B
-    constexpr int KSL = CIN >= 64 ? 64 : CIN;            // input channels per weight stage
+    constexpr int KSL = CIN >= KSLP ? KSLP : CIN;        // input channels per weight stage
     constexpr int SPT = CIN / KSL;                       // stages per tap
     constexpr int NSTAGE = 9 * SPT;
     constexpr int WROWB = KSL * 2, WNCH = KSL / 8;       // weight-slice row bytes / chunks
@@ -313,8 +108,8 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_b(const uint16_t *__restrict
     auto aswz = [&](int row) { return (row / ARP) & (NCH - 1); };
     auto wswz = [&](int row) { return (row / WRP) & (WNCH - 1); };
 
-    constexpr int WINSTR = COUT * WNCH / 256;            // DMA instructions per wave per stage (4 or 1)
-    static_assert(WINSTR * 256 == COUT * WNCH, "weight stage must tile over 256 lanes");
+    constexpr int WINSTR = (COUT * WNCH + NT - 1) / NT;  // DMA instructions per wave per stage
+    constexpr bool WEXACT = (WINSTR * NT == COUT * WNCH);
     auto stage_weights = [&](int st, int buf) {
         const int tap = st / SPT, kb = (st % SPT) * KSL;
         const uint8_t *src = reinterpret_cast<const uint8_t *>(w) + ((size_t)tap * COUT * CIN + kb) * 2;
@@ -322,7 +117,8 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_b(const uint16_t *__restrict
         for (int j = 0; j < WINSTR; j++) {
             const int q0 = (wave * WINSTR + j) * 64;
             const int q = q0 + lane, row = q / WNCH, cp = q % WNCH;
-            dma16(src + (size_t)row * ROWB + ((cp ^ wswz(row)) * 16), wbuf + buf * WBUF_BYTES + q0 * 16);
+            if (WEXACT || q < COUT * WNCH)
+                dma16(src + (size_t)row * ROWB + ((cp ^ wswz(row)) * 16), wbuf + buf * WBUF_BYTES + q0 * 16);
         }
     };
     if (tid < 16) reinterpret_cast<uint4 *>(zrow)[tid] = make_uint4(0, 0, 0, 0);
@@ -402,7 +198,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_b(const uint16_t *__restrict
 #pragma unroll
         for (int sl = 0; sl < SPT; sl++) {
             const int st = tap * SPT + sl;
-            const int buf = (SPT == 2) ? sl : (st & 1);            // compile-time when SPT == 2
+            const int buf = (SPT % 2 == 0) ? (sl & 1) : (st & 1);   // compile-time when SPT is even
             // next stage's weight slice by LDS-DMA into the other buffer.  (Register staging — plain
             // dwordx4 loads + ds_write_b128 at the end of the stage — was measured 1.55x SLOWER here:
             // the wave stalls on the load latency before the barrier; tools/bench_conv.py.)
@@ -500,26 +296,26 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_b(const uint16_t *__restrict
 
 }  // namespace
 
-static int g_conv_variant = 1;      // 0 = 4 boards / workgroup, 1 workgroup / CU; 1 = variant B (default)
+static int g_conv_variant = 1;      // 1 = variant B (2 boards / WG, 2 WG / CU; default: 2 % faster in situ), 2 = variant C (4 boards / WG)
 
 // diagnostic only (not part of the public ABI)
 extern "C" void xq_conv3x3_set_variant(int v) { g_conv_variant = v; }
 
-template <int CIN>
-static int launch_b(hipStream_t s, const void *x, const void *w, const void *bias, const void *residual, void *y,
-                    int n_boards, int relu)
+template <int CIN, int NB, int KSLP, bool STAMP, int ABLATE>
+static int launch_t(hipStream_t s, const void *x, const void *w, const void *bias, const void *residual, void *y,
+                    int n_boards, int relu, void *stamps)
 {
-    constexpr int KSL = CIN >= 64 ? 64 : CIN;
-    constexpr int LDS = 2 * PIX * 256 + 2 * COUT * KSL * 2 + 256 + 512;
+    constexpr int KSL = CIN >= KSLP ? KSLP : CIN;
+    constexpr int LDS = NB * PIX * 256 + 2 * COUT * KSL * 2 + 256 + 512;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv3x3_b<CIN, false>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv3x3_b<CIN, NB, KSLP, STAMP, ABLATE>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return XQ_E_HIP;
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_conv3x3_b<CIN, false>), dim3((n_boards + 1) / 2), dim3(256), LDS, s, (const uint16_t *)x,
-                       (const uint16_t *)w, (const float *)bias, (const uint16_t *)residual, (uint16_t *)y, n_boards,
-                       relu, (unsigned long long *)nullptr);
+    hipLaunchKernelGGL((k_conv3x3_b<CIN, NB, KSLP, STAMP, ABLATE>), dim3((n_boards + NB - 1) / NB), dim3(NB * 128), LDS, s,
+                       (const uint16_t *)x, (const uint16_t *)w, (const float *)bias, (const uint16_t *)residual,
+                       (uint16_t *)y, n_boards, relu, (unsigned long long *)stamps);
     return hipGetLastError() == hipSuccess ? 0 : XQ_E_HIP;
 }
 
@@ -527,90 +323,30 @@ extern "C" int xq_conv3x3_nhwc_bf16(void *stream, const void *x, const void *w, 
                                     void *y, int n_boards, int c_in, int relu)
 {
     if (!x || !w || !bias || !y || n_boards <= 0 || (c_in != 16 && c_in != 128)) return XQ_E_INVALID;
-    if (g_conv_variant == 1) {
-        hipStream_t sb = reinterpret_cast<hipStream_t>(stream);
-        return c_in == 128 ? launch_b<128>(sb, x, w, bias, residual, y, n_boards, relu)
-                           : launch_b<16>(sb, x, w, bias, residual, y, n_boards, relu);
-    }
-    const int grid = (n_boards + BOARDS_PER_WG - 1) / BOARDS_PER_WG;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (c_in == 128) {
-        constexpr int LDS = BOARDS_PER_WG * PIX * 256 + 2 * COUT * 256 + 256;
-        static bool attr_set = false;
-        if (!attr_set) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv3x3<128>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return XQ_E_HIP;
-            attr_set = true;
+    if (c_in == 16) return launch_t<16, 2, 64, false, 0>(s, x, w, bias, residual, y, n_boards, relu, nullptr);
+    if (g_conv_variant == 1) return launch_t<128, 2, 64, false, 0>(s, x, w, bias, residual, y, n_boards, relu, nullptr);
+    return launch_t<128, 4, 128, false, 0>(s, x, w, bias, residual, y, n_boards, relu, nullptr);
+}
+
+// diagnostic only (not part of the public ABI): s_memtime phase stamps, 32 u64 per workgroup;
+// ablate 1 = no stage barriers / weight DMA, 2 = barriers only, 3 = DMA only (results wrong)
+extern "C" int xq_conv3x3_debug_stamps(int variant, int ablate, void *stream, const void *x, const void *w, const void *bias,
+                                       const void *residual, void *y, int n_boards, int relu, void *stamps)
+{
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (variant == 1) {
+        switch (ablate) {
+        case 0: return launch_t<128, 2, 64, true, 0>(s, x, w, bias, residual, y, n_boards, relu, stamps);
+        case 1: return launch_t<128, 2, 64, true, 1>(s, x, w, bias, residual, y, n_boards, relu, stamps);
+        case 2: return launch_t<128, 2, 64, true, 2>(s, x, w, bias, residual, y, n_boards, relu, stamps);
+        default: return launch_t<128, 2, 64, true, 3>(s, x, w, bias, residual, y, n_boards, relu, stamps);
         }
-        hipLaunchKernelGGL(k_conv3x3<128>, dim3(grid), dim3(256), LDS, s, (const uint16_t *)x, (const uint16_t *)w,
-                           (const float *)bias, (const uint16_t *)residual, (uint16_t *)y, n_boards, relu);
-    } else {
-        constexpr int LDS = BOARDS_PER_WG * PIX * 256 + 2 * COUT * 32 + 256;
-        static bool attr_set16 = false;
-        if (!attr_set16) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv3x3<16>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return XQ_E_HIP;
-            attr_set16 = true;
-        }
-        hipLaunchKernelGGL(k_conv3x3<16>, dim3(grid), dim3(256), LDS, s, (const uint16_t *)x, (const uint16_t *)w,
-                           (const float *)bias, (const uint16_t *)residual, (uint16_t *)y, n_boards, relu);
     }
-    return hipGetLastError() == hipSuccess ? 0 : XQ_E_HIP;
-}
-
-// diagnostic only (not part of the public ABI): phase stamps of the c_in = 128 kernel
-extern "C" int xq_conv3x3_debug_stamps(void *stream, const void *x, const void *w, const void *bias, const void *residual,
-                                       void *y, int n_boards, int relu, void *stamps)
-{
-    constexpr int LDS = BOARDS_PER_WG * PIX * 256 + 2 * COUT * 256 + 256;
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv3x3<128, true>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return XQ_E_HIP;
-    const int grid = (n_boards + BOARDS_PER_WG - 1) / BOARDS_PER_WG;
-    hipLaunchKernelGGL((k_conv3x3<128, true>), dim3(grid), dim3(256), LDS, reinterpret_cast<hipStream_t>(stream),
-                       (const uint16_t *)x, (const uint16_t *)w, (const float *)bias, (const uint16_t *)residual,
-                       (uint16_t *)y, n_boards, relu, (unsigned long long *)stamps);
-    return hipGetLastError() == hipSuccess ? 0 : XQ_E_HIP;
-}
-
-// diagnostic only: phase stamps of variant B (c_in = 128): 32 u64 per workgroup
-template <int AB>
-static int launch_dbg_b(void *stream, const void *x, const void *w, const void *bias, const void *residual, void *y,
-                        int n_boards, int relu, void *stamps)
-{
-    constexpr int LDS = 2 * PIX * 256 + 2 * COUT * 64 * 2 + 256 + 512;
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv3x3_b<128, true, AB>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return XQ_E_HIP;
-    hipLaunchKernelGGL((k_conv3x3_b<128, true, AB>), dim3((n_boards + 1) / 2), dim3(256), LDS,
-                       reinterpret_cast<hipStream_t>(stream), (const uint16_t *)x, (const uint16_t *)w, (const float *)bias,
-                       (const uint16_t *)residual, (uint16_t *)y, n_boards, relu, (unsigned long long *)stamps);
-    return hipGetLastError() == hipSuccess ? 0 : XQ_E_HIP;
-}
-// 2 = barriers but no weight DMA; 3 = weight DMA but no barriers (both give wrong results)
-extern "C" int xq_conv3x3_debug_stamps_b_nodma(void *s, const void *x, const void *w, const void *b, const void *r, void *y,
-                                               int n, int relu, void *st) { return launch_dbg_b<2>(s, x, w, b, r, y, n, relu, st); }
-extern "C" int xq_conv3x3_debug_stamps_b_nobar(void *s, const void *x, const void *w, const void *b, const void *r, void *y,
-                                               int n, int relu, void *st) { return launch_dbg_b<3>(s, x, w, b, r, y, n, relu, st); }
-
-extern "C" int xq_conv3x3_debug_stamps_b_nosync(void *stream, const void *x, const void *w, const void *bias,
-                                                const void *residual, void *y, int n_boards, int relu, void *stamps)
-{
-    constexpr int LDS = 2 * PIX * 256 + 2 * COUT * 64 * 2 + 256 + 512;
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv3x3_b<128, true, 1>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return XQ_E_HIP;
-    hipLaunchKernelGGL((k_conv3x3_b<128, true, 1>), dim3((n_boards + 1) / 2), dim3(256), LDS,
-                       reinterpret_cast<hipStream_t>(stream), (const uint16_t *)x, (const uint16_t *)w, (const float *)bias,
-                       (const uint16_t *)residual, (uint16_t *)y, n_boards, relu, (unsigned long long *)stamps);
-    return hipGetLastError() == hipSuccess ? 0 : XQ_E_HIP;
-}
-
-extern "C" int xq_conv3x3_debug_stamps_b(void *stream, const void *x, const void *w, const void *bias, const void *residual,
-                                         void *y, int n_boards, int relu, void *stamps)
-{
-    constexpr int LDS = 2 * PIX * 256 + 2 * COUT * 64 * 2 + 256 + 512;
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv3x3_b<128, true>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return XQ_E_HIP;
-    hipLaunchKernelGGL((k_conv3x3_b<128, true>), dim3((n_boards + 1) / 2), dim3(256), LDS,
-                       reinterpret_cast<hipStream_t>(stream), (const uint16_t *)x, (const uint16_t *)w, (const float *)bias,
-                       (const uint16_t *)residual, (uint16_t *)y, n_boards, relu, (unsigned long long *)stamps);
-    return hipGetLastError() == hipSuccess ? 0 : XQ_E_HIP;
+    switch (ablate) {
+    case 0: return launch_t<128, 4, 128, true, 0>(s, x, w, bias, residual, y, n_boards, relu, stamps);
+    case 1: return launch_t<128, 4, 128, true, 1>(s, x, w, bias, residual, y, n_boards, relu, stamps);
+    case 2: return launch_t<128, 4, 128, true, 2>(s, x, w, bias, residual, y, n_boards, relu, stamps);
+    default: return launch_t<128, 4, 128, true, 3>(s, x, w, bias, residual, y, n_boards, relu, stamps);
+    }
 }

@@ -150,6 +150,7 @@ class InferenceNet(nn.Module):
         self.use_hip_conv = (dtype == torch.bfloat16 and c_in == 16 and str(device).startswith("cuda")
                              and net.conv1.out_channels == 128)
         self._buf = None
+        self.tower_events = None
         if self.use_hip_conv:
             self.hip_w = [w.permute(2, 3, 0, 1).reshape(9, w.shape[0], w.shape[1]).to(device=device, dtype=dtype).contiguous()
                           for w, _ in convs]
@@ -190,10 +191,17 @@ class InferenceNet(nn.Module):
                                               res.data_ptr() if res is not None else None, dst.data_ptr(), g, cin, 1))
         conv(xin, a, 0, None, 16)
         cur, t1, t2 = a, b, c
+        ev = None
+        if self.tower_events is not None:                 # bench.py: HIP events around the 128-ch convs
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         for i in range(self.n_blocks):
             conv(cur, t1, 1 + 2 * i, None, 128)
             conv(t1, t2, 2 + 2 * i, cur, 128)             # relu(conv + bias + residual)
             cur, t2 = t2, cur
+        if ev is not None:
+            ev[1].record()
+            self.tower_events.append(ev)
         return cur.permute(0, 3, 1, 2)                    # logical NCHW, channels-last strides
 
     @torch.no_grad()

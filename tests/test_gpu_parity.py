@@ -390,7 +390,7 @@ def test_fused_conv_kernel_vs_torch(L):
     from chinesechessai_amd import _lib
     torch.manual_seed(1)
     st = torch.cuda.current_stream().cuda_stream
-    for variant in (1, 0):
+    for variant in (2, 1):
         L.xq_conv3x3_set_variant(variant)
         for cin, G in ((128, 37), (16, 37), (128, 1), (128, 8)):
             x = (torch.randn(G, 10, 9, cin, device="cuda") * 0.5).bfloat16()

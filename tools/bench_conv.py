@@ -36,7 +36,7 @@ for cin in (128, 16):
     y = torch.empty(G, 10, 9, 128, device="cuda", dtype=torch.bfloat16)
     n = min(G, 512)
     fl = 2.0 * G * 90 * 128 * 9 * cin
-    for variant in (0, 1):
+    for variant in (1, 2):
         L.xq_conv3x3_set_variant(variant)
         for use_res in (False, True):
             y.zero_()
@@ -69,25 +69,22 @@ wk = w.permute(2, 3, 0, 1).reshape(9, 128, cin).contiguous()
 b = torch.randn(128, device="cuda") * 0.1
 r = torch.relu(torch.randn(G, 10, 9, 128, device="cuda") * 0.5).bfloat16()
 y = torch.empty(G, 10, 9, 128, device="cuda", dtype=torch.bfloat16)
-for name, nper, slots, last, rt0, rt1, nwg in (("xq_conv3x3_debug_stamps", 16, 13, 12, 13, 14, (G + 3) // 4),
-                                               ("xq_conv3x3_debug_stamps_b", 32, 24, 23, 24, 25, (G + 1) // 2),
-                                               ("xq_conv3x3_debug_stamps_b_nosync", 32, 24, 23, 24, 25, (G + 1) // 2),
-                                               ("xq_conv3x3_debug_stamps_b_nodma", 32, 24, 23, 24, 25, (G + 1) // 2),
-                                               ("xq_conv3x3_debug_stamps_b_nobar", 32, 24, 23, 24, 25, (G + 1) // 2)):
-    stamps = torch.zeros(nwg * nper, dtype=torch.int64, device="cuda")
-    fn = getattr(L, name)
-    fn.argtypes = [C.c_void_p] * 6 + [C.c_int, C.c_int, C.c_void_p]
-    for _ in range(2):
-        fn(st, x.data_ptr(), wk.data_ptr(), b.data_ptr(), r.data_ptr(), y.data_ptr(), G, 1, stamps.data_ptr())
-    torch.cuda.synchronize()
-    s = stamps.cpu().numpy().reshape(nwg, nper)
-    d = np.diff(s[:, :slots], axis=1).astype(np.float64)
-    print(name, "phase medians (shader cycles):", " ".join("%d" % np.median(d[:, i]) for i in range(d.shape[1])))
-    if nper == 32:
-        print("   B: prologue %d | stages sum %d | acc->LDS %d | barrier %d | rows->global %d" % (
-            np.median(d[:, 0]), np.median(d[:, 1:19].sum(axis=1)), np.median(s[:, 21] - s[:, 20]),
-            np.median(s[:, 22] - s[:, 21]), np.median(s[:, 23] - s[:, 22])))
-    rt = (s[:, rt1] - s[:, rt0]).astype(np.float64)
-    tot = (s[:, last] - s[:, 0]).astype(np.float64)
-    print("   per-WG total median %.0f cycles, clock %.3f GHz, kernel wall %.1f us" % (
-        np.median(tot), np.median(tot / rt * 0.1), (s[:, rt1].max() - s[:, rt0].min()) / 100.0))
+fn = L.xq_conv3x3_debug_stamps
+fn.argtypes = [C.c_int, C.c_int] + [C.c_void_p] * 6 + [C.c_int, C.c_int, C.c_void_p]
+for variant, nb, nst in ((1, 2, 18), (2, 4, 9)):
+    for ablate in (0, 1, 2, 3):
+        nwg = (G + nb - 1) // nb
+        stamps = torch.zeros(nwg * 32, dtype=torch.int64, device="cuda")
+        for _ in range(2):
+            fn(variant, ablate, st, x.data_ptr(), wk.data_ptr(), b.data_ptr(), r.data_ptr(), y.data_ptr(), G, 1,
+               stamps.data_ptr())
+        torch.cuda.synchronize()
+        s = stamps.cpu().numpy().reshape(nwg, 32).astype(np.float64)
+        stages = s[:, 1 + nst] - s[:, 1]
+        rt = s[:, 25] - s[:, 24]
+        tot = s[:, 23] - s[:, 0]
+        print("variant %d ablate %d: prologue %d | %d stages %d | acc->LDS %d | barrier %d | rows->global %d | WG total %d "
+              "cycles, clock %.3f GHz, kernel wall %.1f us" % (
+                  variant, ablate, np.median(s[:, 1] - s[:, 0]), nst, np.median(stages), np.median(s[:, 21] - s[:, 20]),
+                  np.median(s[:, 22] - s[:, 21]), np.median(s[:, 23] - s[:, 22]), np.median(tot),
+                  np.median(tot / rt * 0.1), (s[:, 25].max() - s[:, 24].min()) / 100.0))
