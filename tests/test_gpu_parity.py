@@ -87,6 +87,86 @@ def test_edge_boards(L, golden_dir):
             assert st[j, 7] == m["reason"]
 
 
+def test_random_boards_vs_oracle(L):
+    """20,000 seeded random boards that are NOT restricted to reachable play — random piece
+    counts (up to 3 rooks / cannons / knights per side, pieces anywhere, kings possibly outside the
+    palace or missing from the cache, stale caches) — legal moves, in-check for both sides, kings
+    facing: HIP == oracle.  Then one make_move per board (random legal move, random
+    consecutive_checks / no_capture / move_count incl. 69 and 99): reward bits, done, winner,
+    reason, caches, next legal moves."""
+    from chinesechessai_amd import _lib
+    from oracle import xq_oracle as xo
+    rng = np.random.RandomState(12345)
+    n = 20000
+    boards = np.zeros((n, 90), np.int8)
+    player = rng.choice([1, -1], size=n).astype(np.int32)
+    rk = np.zeros(n, np.int32)
+    bk = np.zeros(n, np.int32)
+    for i in range(n):
+        sqs = rng.permutation(90)
+        k = 0
+        b = boards[i]
+        if rng.rand() < 0.9:
+            rsq = (7 + rng.randint(3)) * 9 + 3 + rng.randint(3)
+            bsq = rng.randint(3) * 9 + 3 + rng.randint(3)
+        else:
+            rsq, bsq = int(sqs[88]), int(sqs[89])
+        b[rsq] = 1
+        b[bsq] = -1 if bsq != rsq else 1
+        npieces = rng.randint(0, 26)
+        for _ in range(npieces):
+            s_ = int(sqs[k]); k += 1
+            if b[s_] != 0:
+                continue
+            t = int(rng.choice([2, 3, 4, 5, 6, 7, 4, 5, 6, 7]))
+            b[s_] = t * int(rng.choice([1, -1]))
+        mode = rng.rand()
+        rk[i] = rsq if mode < 0.85 else (-1 if mode < 0.9 else int(sqs[87]))
+        bk[i] = bsq if (mode < 0.85 or mode > 0.95) else (-1 if mode < 0.9 else int(sqs[86]))
+    moves, counts = _legal_batch(L, boards, player, rk, bk)
+    a, b_, f = (np.zeros(n, np.int32) for _ in range(3))
+    _lib.check(L.xq_rules_query(n, _lib.ptr(boards), _lib.ptr(player), _lib.ptr(rk), _lib.ptr(bk),
+                                _lib.ptr(a), _lib.ptr(b_), _lib.ptr(f)))
+    env = xo.OracleEnv()
+    OL = xo.lib()
+    pick = np.zeros(n, np.int32)
+    st = np.zeros((n, 10), np.int32)
+    exp = []
+    for i in range(n):
+        env.set_state(boards[i], player[i], red_king=rk[i], black_king=bk[i])
+        lm = env.legal_moves()
+        assert lm == moves[i, :counts[i]].tolist(), i
+        assert bool(OL.xqo_is_in_check(env.p, 1)) == bool(a[i]), i
+        assert bool(OL.xqo_is_in_check(env.p, -1)) == bool(b_[i]), i
+        assert bool(OL.xqo_are_kings_facing(env.p)) == bool(f[i]), i
+        mc = int(rng.choice([0, 5, 68, 69, 70]))
+        nc = int(rng.choice([0, 3, 98, 99]))
+        cc = int(rng.randint(0, 4))
+        if lm:
+            mv = lm[rng.randint(len(lm))]
+        else:
+            mv = 0 * 90 + 1          # any move: make_move does not validate (SURVEY.md §8b Errors)
+        pick[i] = mv
+        st[i, :7] = [player[i], mc, 2, rk[i], bk[i], nc, cc]
+        env.set_state(boards[i], player[i], move_count=mc, red_king=rk[i], black_king=bk[i], no_capture=nc,
+                      consecutive_checks=cc)
+        reward, done, chk = env.make_move(mv)
+        e = env.e
+        exp.append((reward, done, chk, e.winner, e.end_reason, e.red_king, e.black_king, e.no_capture_count,
+                    e.consecutive_checks, env.board().reshape(90).copy(), env.legal_moves() if abs(boards[i][mv % 90]) != 1 else None))
+    bb = boards.copy()
+    out = _make_move_batch(L, bb, st, pick, None, None)
+    for i, (reward, done, chk, winner, reason, erk, ebk, nc2, cc2, eb, nxt) in enumerate(exp):
+        assert bits(out["reward"][i]) == bits(reward), (i, out["reward"][i], reward)
+        assert bool(out["done"][i]) == done and bool(out["is_check"][i]) == chk, i
+        assert st[i, 2] == winner and st[i, 3] == erk and st[i, 4] == ebk and st[i, 5] == nc2 and st[i, 6] == cc2, i
+        if done:
+            assert st[i, 7] == reason, i
+        assert np.array_equal(bb[i], eb), i
+        if nxt is not None:
+            assert out["next_moves"][i, :out["next_n"][i]].tolist() == nxt, i
+
+
 def _make_move_batch(L, boards, state, move, pos_hist, chk_hist, n_hist=None, n_chk=None):
     from chinesechessai_amd import _lib
     n = len(move)
