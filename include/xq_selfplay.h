@@ -217,6 +217,24 @@ int  xq_engine_pack_samples(xq_engine *e, void *records_dev /* xq_sample_record[
 int  xq_conv3x3_nhwc_bf16(void *hip_stream, const void *x_dev, const void *w_dev, const void *bias_dev,
                           const void *residual_dev, void *y_dev, int n_boards, int c_in, int relu);
 
+/* ------------------------------------------------------------------------------------------
+ * Replay buffer: device-resident mirror of trainer.py's ReplayBuffer
+ * (trainer.py:22-44: deque(maxlen) of samples, push appends a game's samples in order) and of the
+ * batch formation in Trainer.train_network (trainer.py:309-321: encode_board(board, 1) for every
+ * sampled board, float32 reward as the value target).  Records are xq_sample_record.
+ * ------------------------------------------------------------------------------------------ */
+const char *xq_replay_last_error(void);
+int     xq_replay_create(int device, int64_t capacity, void **out);
+void    xq_replay_destroy(void *rb);
+int64_t xq_replay_size(void *rb);                       /* len(buffer) */
+/* push every valid record of records_dev [n_games][70] in game / ply order (drop-oldest) */
+int     xq_replay_push_records(void *rb, void *hip_stream, const void *records_dev, int n_games, int64_t *n_pushed);
+/* states float32 [batch][15][10][9], targets float32 [batch][1] for deque indices idx_host[] */
+int     xq_replay_encode_batch(void *rb, void *hip_stream, const int64_t *idx_host, int batch, void *states_dev,
+                               void *targets_dev);
+/* compatibility view: the records at deque indices idx_host[] copied to host memory */
+int     xq_replay_read_records(void *rb, void *hip_stream, const int64_t *idx_host, int batch, void *records_host);
+
 /* ---- measurement: HIP events recorded on the engine's stream around every tree-kernel launch ---- */
 int  xq_engine_profile(xq_engine *e, int enable);
 int  xq_engine_profile_read(xq_engine *e, double *search_ms_total, int64_t *search_launches,

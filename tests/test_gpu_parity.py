@@ -561,3 +561,68 @@ def test_full_size_properties(L):
         for i in range(3):
             k = og.s_nmoves[i]
             assert list(og.t_visits[i][:k]) == b.s_counts[g, i, :k].tolist()
+
+
+def test_replay_buffer_vs_reference_semantics(L):
+    """the device-resident ReplayBuffer against a restatement of
+    trainer.py:22-44 (deque(maxlen), push in game order, np.random.choice indices) and of the batch
+    formation trainer.py:313-321 (encode_board(board, 1), float32 rewards) — bit-exact tensors,
+    including wrap-around, overflow by more than the capacity in one push, and tuple pushes."""
+    import collections
+    import torch
+    from chinesechessai_amd import _lib
+    from chinesechessai_amd.engine import HashNetEvaluator, SelfPlayEngine
+    from chinesechessai_amd.neural_network import ChessNet
+    from chinesechessai_amd.replay import ReplayBuffer
+    from chinesechessai_amd import distributed as xd
+
+    def play(n, seed0, max_moves):
+        eng = SelfPlayEngine(n, sims=16, max_moves=max_moves)
+        b = eng.play(HashNetEvaluator(), np.arange(seed0, seed0 + n, dtype=np.uint32))
+        rec = torch.zeros(n * _lib.MAX_PLIES * xd.RECORD_BYTES, dtype=torch.uint8, device="cuda")
+        eng.pack_samples(rec.data_ptr())
+        torch.cuda.synchronize()
+        eng.close()
+        return b, rec
+
+    for cap in (500, 90, 5000):
+        buf = ReplayBuffer(max_size=cap)
+        ref = collections.deque(maxlen=cap)
+        for rnd, (n, mm) in enumerate(((7, 70), (5, 13), (3, 70), (9, 30))):
+            b, rec = play(n, 100 * rnd, mm)
+            pushed = buf.push_records(rec, n)
+            k = 0
+            for g in range(n):
+                for smp in b.game_data(g):
+                    ref.append(smp)
+                    k += 1
+            assert pushed == k and len(buf) == len(ref), (cap, rnd, pushed, k, len(buf), len(ref))
+            bs = min(64, len(ref))
+            np.random.seed(7 + rnd)
+            states, targets = buf.sample_tensors(bs)
+            np.random.seed(7 + rnd)
+            idx = np.random.choice(len(ref), bs, replace=False)
+            exp_states = np.stack([ChessNet.encode_board(ref[i][0], 1) for i in idx]).astype(np.float32)
+            exp_targets = torch.FloatTensor([ref[i][2] for i in idx]).unsqueeze(1).numpy()
+            assert np.array_equal(states.cpu().numpy(), exp_states), (cap, rnd)
+            assert np.array_equal(targets.cpu().numpy(), exp_targets), (cap, rnd)
+            np.random.seed(11)
+            boards, probs, rewards = buf.sample(min(16, len(ref)))
+            np.random.seed(11)
+            idx = np.random.choice(len(ref), min(16, len(ref)), replace=False)
+            for j, i in enumerate(idx):
+                assert np.array_equal(boards[j], ref[i][0]) and rewards[j] == ref[i][2]
+                assert list(probs[j].keys()) == list(ref[i][1].keys())
+                assert list(probs[j].values()) == list(ref[i][1].values())
+        # reference-format tuples pushed from the host
+        game = [(ref[i][0], ref[i][1], ref[i][2]) for i in range(min(5, len(ref)))]
+        buf.push(game)
+        for smp in game:
+            ref.append(smp)
+        assert len(buf) == len(ref)
+        st2, tg2 = buf.sample_tensors(len(ref), indices=np.arange(len(ref)))
+        assert np.array_equal(st2.cpu().numpy(), np.stack([ChessNet.encode_board(x[0], 1) for x in ref]).astype(np.float32))
+        assert np.array_equal(tg2.cpu().numpy(), torch.FloatTensor([x[2] for x in ref]).unsqueeze(1).numpy())
+        with pytest.raises(_lib.XqError):
+            buf.sample_tensors(2, indices=np.array([0, len(ref)]))
+        buf.close()
