@@ -117,6 +117,7 @@ _SIGNATURES = {
     "xq_engine_pack_samples": (C.c_int, [C.c_void_p, C.c_void_p]),
     "xq_conv3x3_nhwc_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_int, C.c_int, C.c_int]),
+    "xq_heads_nhwc_bf16": (C.c_int, [C.c_void_p] * 6 + [C.c_int]),
     "xq_replay_last_error": (C.c_char_p, []),
     "xq_replay_create": (C.c_int, [C.c_int, C.c_int64, C.POINTER(C.c_void_p)]),
     "xq_replay_destroy": (None, [C.c_void_p]),

@@ -294,6 +294,101 @@ __global__ __launch_bounds__(NB * 128, 2) void k_conv3x3_b(const uint16_t *__res
     stamp(23);
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Heads: the policy (128->32) and value (128->8) 1x1 convolutions + folded BN + ReLU
+// (neural_network.py:61,66) as ONE pass over the tower output, written directly in the layouts the
+// two fully-connected layers consume: P [G][90*32] and V [G][90*8] (h, w, c order; the FC weights
+// are permuted once on the host).  Memory-bound: 23 KB in, 7.2 KB out per board.
+//   workgroup = 4 waves = 4 boards; a wave DMA's its board into LDS (swizzled) and runs
+//   3 pixel tiles x 2 channel tiles x 8 k-steps of v_mfma_f32_32x32x16_bf16 (D = W . X^T);
+//   weights [64 rows (40 used)][128] are staged once per workgroup.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 1) void k_heads(const uint16_t *__restrict__ x, const uint16_t *__restrict__ w,
+                                                  const float *__restrict__ bias, uint16_t *__restrict__ P,
+                                                  uint16_t *__restrict__ V, int G)
+{
+    constexpr int ACT_BYTES = PIX * 256;
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    uint8_t *wl = lds + 4 * ACT_BYTES;                                    // [64][256 B], swizzled
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int board = blockIdx.x * 4 + wave;
+    const bool board_ok = board < G;
+    uint8_t *my_act = lds + wave * ACT_BYTES;
+    {   // weights: 64 rows x 16 chunks = 1024 chunks = 4 DMA pieces per wave
+        const uint8_t *src = reinterpret_cast<const uint8_t *>(w);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int q0 = (wave * 4 + j) * 64, q = q0 + lane, row = q >> 4, cp = q & 15;
+            dma16(src + row * 256 + ((cp ^ (row & 15)) * 16), wl + q0 * 16);
+        }
+    }
+    if (board_ok) {
+        const uint8_t *src = reinterpret_cast<const uint8_t *>(x) + (size_t)board * PIX * 256;
+#pragma unroll
+        for (int j = 0; j < 23; j++) {
+            const int q = j * 64 + lane, p = q >> 4, cp = q & 15;
+            if (q < PIX * 16) dma16(src + p * 256 + ((cp ^ (p & 15)) * 16), my_act + j * 1024);
+        }
+    }
+    const int r32 = lane & 31, h = lane >> 5;
+    f32x16 acc[2][3];
+#pragma unroll
+    for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+        for (int nt = 0; nt < 3; nt++)
+#pragma unroll
+            for (int i = 0; i < 16; i++) acc[mt][nt][i] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 8; kk++) {
+        const int c = kk * 2 + h;
+        bf16x8 bf[3], af[2];
+#pragma unroll
+        for (int nt = 0; nt < 3; nt++) {
+            const int p = nt * 32 + r32;                 // rows >= 90 read neighbouring LDS: discarded
+            bf[nt] = *reinterpret_cast<const bf16x8 *>(my_act + p * 256 + ((c ^ (p & 15)) * 16));
+        }
+#pragma unroll
+        for (int mt = 0; mt < 2; mt++) {
+            const int row = mt * 32 + r32;
+            af[mt] = *reinterpret_cast<const bf16x8 *>(wl + row * 256 + ((c ^ (row & 15)) * 16));
+        }
+#pragma unroll
+        for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+            for (int nt = 0; nt < 3; nt++)
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mt], bf[nt], acc[mt][nt], 0, 0, 0);
+    }
+    if (!board_ok) return;
+    // lane holds pixel p and channels mt*32 + 8q + 4h + (0..3): policy = channels 0..31, value = 32..39
+    uint8_t *Pb = reinterpret_cast<uint8_t *>(P) + (size_t)board * PIX * 64;
+    uint8_t *Vb = reinterpret_cast<uint8_t *>(V) + (size_t)board * PIX * 16;
+#pragma unroll
+    for (int nt = 0; nt < 3; nt++) {
+        const int p = nt * 32 + r32;
+        if (p < PIX) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int c0 = 8 * q + 4 * h;
+                const f32x4 b4 = *reinterpret_cast<const f32x4 *>(bias + c0);
+                float v0 = acc[0][nt][4 * q + 0] + b4[0], v1 = acc[0][nt][4 * q + 1] + b4[1];
+                float v2 = acc[0][nt][4 * q + 2] + b4[2], v3 = acc[0][nt][4 * q + 3] + b4[3];
+                v0 = v0 > 0.f ? v0 : 0.f; v1 = v1 > 0.f ? v1 : 0.f; v2 = v2 > 0.f ? v2 : 0.f; v3 = v3 > 0.f ? v3 : 0.f;
+                *reinterpret_cast<uint2 *>(Pb + p * 64 + c0 * 2) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+            }
+            {
+                const int c0 = 32 + 4 * h;
+                const f32x4 b4 = *reinterpret_cast<const f32x4 *>(bias + c0);
+                float v0 = acc[1][nt][0] + b4[0], v1 = acc[1][nt][1] + b4[1];
+                float v2 = acc[1][nt][2] + b4[2], v3 = acc[1][nt][3] + b4[3];
+                v0 = v0 > 0.f ? v0 : 0.f; v1 = v1 > 0.f ? v1 : 0.f; v2 = v2 > 0.f ? v2 : 0.f; v3 = v3 > 0.f ? v3 : 0.f;
+                *reinterpret_cast<uint2 *>(Vb + p * 16 + 4 * h * 2) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+            }
+        }
+    }
+}
+
 }  // namespace
 
 static int g_conv_variant = 1;      // 1 = variant B (2 boards / WG, 2 WG / CU; default: 2 % faster in situ), 2 = variant C (4 boards / WG)
@@ -349,4 +444,22 @@ extern "C" int xq_conv3x3_debug_stamps(int variant, int ablate, void *stream, co
     case 2: return launch_t<128, 4, 128, true, 2>(s, x, w, bias, residual, y, n_boards, relu, stamps);
     default: return launch_t<128, 4, 128, true, 3>(s, x, w, bias, residual, y, n_boards, relu, stamps);
     }
+}
+
+extern "C" int xq_heads_nhwc_bf16(void *stream, const void *x, const void *w, const void *bias, void *policy_out,
+                                  void *value_out, int n_boards)
+{
+    if (!x || !w || !bias || !policy_out || !value_out || n_boards <= 0) return XQ_E_INVALID;
+    constexpr int LDS = 4 * PIX * 256 + 64 * 256;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_heads), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) !=
+            hipSuccess)
+            return XQ_E_HIP;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_heads, dim3((n_boards + 3) / 4), dim3(256), LDS, reinterpret_cast<hipStream_t>(stream),
+                       (const uint16_t *)x, (const uint16_t *)w, (const float *)bias, (uint16_t *)policy_out,
+                       (uint16_t *)value_out, n_boards);
+    return hipGetLastError() == hipSuccess ? 0 : XQ_E_HIP;
 }

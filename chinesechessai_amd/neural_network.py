@@ -150,6 +150,7 @@ class InferenceNet(nn.Module):
         self.use_hip_conv = (dtype == torch.bfloat16 and c_in == 16 and str(device).startswith("cuda")
                              and net.conv1.out_channels == 128)
         self._buf = None
+        self._hbuf = None
         self.tower_events = None
         if self.use_hip_conv:
             self.hip_w = [w.permute(2, 3, 0, 1).reshape(9, w.shape[0], w.shape[1]).to(device=device, dtype=dtype).contiguous()
@@ -160,6 +161,13 @@ class InferenceNet(nn.Module):
         vw, vb = _fold_bn(net.value_conv, net.value_bn)
         hw = torch.cat([pw, vw], 0)
         hb = torch.cat([pb, vb], 0)
+        if self.use_hip_conv:
+            hw64 = torch.zeros((64, hw.shape[1]), dtype=torch.float64)
+            hw64[:40] = hw.reshape(40, -1)
+            hb64 = torch.zeros(64, dtype=torch.float64)
+            hb64[:40] = hb
+            self.hip_hw = hw64.to(device=device, dtype=dtype).contiguous()
+            self.hip_hb = hb64.to(device=device, dtype=torch.float32).contiguous()
         self.hw = nn.Parameter(hw.to(device=device, dtype=dtype).contiguous(memory_format=cl), requires_grad=False)
         self.hb = nn.Parameter(hb.to(device=device, dtype=dtype), requires_grad=False)
         # policy FC consumes the NHWC-flattened activation: permute its input columns once
@@ -214,15 +222,29 @@ class InferenceNet(nn.Module):
                 y = F.relu(F.conv2d(x, self.cw[1 + 2 * i], self.cb[1 + 2 * i], padding=1))
                 y = F.conv2d(y, self.cw[2 + 2 * i], self.cb[2 + 2 * i], padding=1)
                 x = F.relu(y + x)
-        h = F.relu(F.conv2d(x, self.hw, self.hb))                  # [G, 40, 10, 9] channels-last
-        h = h.permute(0, 2, 3, 1)                                   # [G, 10, 9, 40] view
-        g = h.shape[0]
-        hp = h[..., :32].reshape(g, 2880)
+        g = x.shape[0]
+        if self.use_hip_conv and x.is_cuda:
+            # fused heads kernel: both 1x1 convs + ReLU, outputs already in the FC input layouts
+            from . import _lib
+            if self._hbuf is None or self._hbuf[0].shape[0] != g:
+                self._hbuf = (torch.empty((g, 2880), dtype=torch.bfloat16, device=x.device),
+                              torch.empty((g, 720), dtype=torch.bfloat16, device=x.device))
+            hp, hv = self._hbuf
+            xin = x.permute(0, 2, 3, 1)
+            assert xin.is_contiguous()
+            _lib.check(_lib.lib().xq_heads_nhwc_bf16(torch.cuda.current_stream().cuda_stream, xin.data_ptr(),
+                                                     self.hip_hw.data_ptr(), self.hip_hb.data_ptr(), hp.data_ptr(),
+                                                     hv.data_ptr(), g))
+        else:
+            h = F.relu(F.conv2d(x, self.hw, self.hb))              # [G, 40, 10, 9] channels-last
+            h = h.permute(0, 2, 3, 1)                               # [G, 10, 9, 40] view
+            hp = h[..., :32].reshape(g, 2880)
+            hv = h[..., 32:].reshape(g, 720)
         if out_logits is not None:
             policy = torch.addmm(self.pfb, hp, self.pfw.t(), out=out_logits)   # no extra 265 MB copy
         else:
             policy = F.linear(hp, self.pfw, self.pfb)
-        v = F.relu(F.linear(h[..., 32:].reshape(g, 720), self.v1w, self.v1b))
+        v = F.relu(F.linear(hv, self.v1w, self.v1b))
         v = torch.tanh(F.linear(v, self.v2w, self.v2b)).reshape(g)
         if out_values is not None:
             out_values.copy_(v)

@@ -217,6 +217,13 @@ int  xq_engine_pack_samples(xq_engine *e, void *records_dev /* xq_sample_record[
 int  xq_conv3x3_nhwc_bf16(void *hip_stream, const void *x_dev, const void *w_dev, const void *bias_dev,
                           const void *residual_dev, void *y_dev, int n_boards, int c_in, int relu);
 
+/* The two 1x1 head convolutions (policy 128->32, value 128->8; neural_network.py:34,42,61,66) with
+ * folded BN and ReLU in one pass: x [n][10][9][128] bf16, w [64][128] bf16 (rows 0..31 policy,
+ * 32..39 value, rest zero), bias float32[64] -> policy_out [n][90][32] bf16, value_out [n][90][8]
+ * bf16 (the (h, w, c) order the permuted FC weights expect). */
+int  xq_heads_nhwc_bf16(void *hip_stream, const void *x_dev, const void *w_dev, const void *bias_dev,
+                        void *policy_out_dev, void *value_out_dev, int n_boards);
+
 /* ------------------------------------------------------------------------------------------
  * Replay buffer: device-resident mirror of trainer.py's ReplayBuffer
  * (trainer.py:22-44: deque(maxlen) of samples, push appends a game's samples in order) and of the

@@ -497,6 +497,31 @@ def test_fused_conv_kernel_vs_torch(L):
     assert L.xq_conv3x3_nhwc_bf16(st, x.data_ptr(), wk.data_ptr(), b.data_ptr(), None, y.data_ptr(), 4, 64, 1) == -1
 
 
+def test_fused_heads_kernel_vs_torch(L):
+    """k_heads: both 1x1 head convolutions + bias + ReLU, outputs in the (h, w, c) FC layouts, against
+    an fp32 torch reference on the same bf16 inputs (atol 2^-7 relative to magnitude <= 4: one bf16
+    rounding); odd board counts; nothing written past the end."""
+    import torch
+    from chinesechessai_amd import _lib
+    torch.manual_seed(2)
+    st = torch.cuda.current_stream().cuda_stream
+    for G in (1, 5, 64):
+        x = torch.relu(torch.randn(G, 10, 9, 128, device="cuda") * 0.7).bfloat16()
+        w = torch.zeros(64, 128, device="cuda")
+        w[:40] = torch.randn(40, 128, device="cuda") / 8
+        w = w.bfloat16()
+        b = torch.zeros(64, device="cuda")
+        b[:40] = torch.randn(40, device="cuda") * 0.2
+        P = torch.full((G + 1, 2880), 9.0, device="cuda", dtype=torch.bfloat16)
+        V = torch.full((G + 1, 720), 9.0, device="cuda", dtype=torch.bfloat16)
+        _lib.check(L.xq_heads_nhwc_bf16(st, x.data_ptr(), w.data_ptr(), b.data_ptr(), P.data_ptr(), V.data_ptr(), G))
+        torch.cuda.synchronize()
+        ref = torch.relu(x.float().reshape(G, 90, 128) @ w.float().t() + b)            # [G, 90, 64]
+        assert (P[:G].float().reshape(G, 90, 32) - ref[..., :32]).abs().max().item() <= 2 ** -7 * max(1.0, ref.abs().max().item())
+        assert (V[:G].float().reshape(G, 90, 8) - ref[..., 32:40]).abs().max().item() <= 2 ** -7 * max(1.0, ref.abs().max().item())
+        assert (P[G] == 9.0).all() and (V[G] == 9.0).all()
+
+
 def test_real_network_game_runs_and_invariants(L):
     """Statistical parity with the real net is bounded by H2: here the invariants
     every reference game satisfies — visit totals S-8 per ply (A10), pi sums to 1, z from the
