@@ -705,3 +705,34 @@ def test_real_network_fp32_games_track_the_cpu_reference_algorithm(L):
                 total += min(og.n_plies, int(b.n_plies[g])) - i - 1      # plies after a divergence count as different
                 break
     assert same / total >= 0.8, (same, total)
+
+
+def test_arena_callers_vs_oracle(L):
+    """evaluate.py's and compare_models.py's game loops on the engine.  With
+    exact evaluators (HashNet salt 0 = red, salt 1 = black) the statistics must equal the ones the
+    CPU oracle's games give for the same seeds and temperatures (0.1 / 0.3, NumPy pow tables)."""
+    from chinesechessai_amd.arena import evaluate_games, play_match
+    from chinesechessai_amd.engine import HashNetEvaluator
+    from oracle import xq_oracle as xo
+    from tests.test_oracle_search import _salted
+    seeds = list(range(300, 312))
+    S = 24
+    tab01 = np.arange(S + 1, dtype=np.int64) ** (1.0 / 0.1)
+    tab03 = np.arange(S + 1, dtype=np.int64) ** (1.0 / 0.3)
+    st = evaluate_games(HashNetEvaluator(0), num_games=len(seeds), temperature=0.1, num_simulations=S, seeds=seeds)
+    ow, on = [], []
+    for sd in seeds:
+        rc, g = xo.self_play_game(sd, S, temperature=0.1, pow_table=tab01)
+        ow.append(g.winner); on.append(g.n_samples)
+    assert st["red_wins"] == ow.count(1) and st["black_wins"] == ow.count(-1) and st["draws"] == ow.count(0)
+    assert st["avg_moves"] == float(np.mean(on)) and st["min_moves"] == min(on) and st["max_moves"] == max(on)
+    assert len(st["end_reasons"]) == len(seeds) and all(isinstance(x, str) for x in st["end_reasons"])
+    res = play_match(HashNetEvaluator(0), HashNetEvaluator(1), num_games=len(seeds), verbose=False,
+                     num_simulations=S, seeds=seeds)
+    ow, op = [], []
+    for sd in seeds:
+        rc, g = xo.self_play_game(sd, S, temperature=0.3, eval_black=_salted(1), pow_table=tab03)
+        ow.append(g.winner); op.append(g.n_plies)
+    assert res["model1_wins"] == ow.count(1) and res["model2_wins"] == ow.count(-1) and res["draws"] == ow.count(0)
+    assert res["avg_moves"] == float(np.sum(op) / len(seeds))
+    assert set(res) == {"model1_wins", "model2_wins", "draws", "avg_moves", "model1_winrate", "model2_winrate", "draw_rate"}
