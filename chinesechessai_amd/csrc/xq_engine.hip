@@ -77,6 +77,10 @@ struct Eng {
     uint32_t *s_board; int8_t *s_player; uint8_t *s_n; uint16_t *s_moves; uint16_t *s_counts; double *s_z;
     double   *step_reward; uint16_t *t_move;
     const double *pow_table; int pow_n;
+    // opt-in search extensions with no counterpart in the reference (BASELINE C5);
+    // noise_eps == 0 keeps the reference behaviour
+    double noise_alpha, noise_eps;
+    uint64_t noise_seed;
 };
 
 struct __align__(16) WaveLds {
@@ -270,9 +274,31 @@ __device__ void backup(const Tree &T, const uint16_t *path_node, int depth, doub
     mem_fence_wave();
 }
 
+// ---- Dirichlet root noise (AlphaZero extension; absent from the reference) ------------------
+__device__ __forceinline__ float u01(uint64_t key)
+{
+    return ((float)(mix64(key) >> 40) + 0.5f) * (1.0f / 16777216.0f);          // (0, 1)
+}
+
+// Gamma(alpha, 1) by Marsaglia-Tsang on alpha + 1 and the U^(1/alpha) boost; counter-based stream
+__device__ float gamma_sample(float alpha, uint64_t key)
+{
+    const float d = alpha + 1.0f - 1.0f / 3.0f, c = 1.0f / sqrtf(9.0f * d);
+    float g = d;
+    for (int t = 0; t < 16; t++) {
+        const float u1 = u01(key + 4 * t + 1), u2 = u01(key + 4 * t + 2), u3 = u01(key + 4 * t + 3);
+        const float x = sqrtf(-2.0f * logf(u1)) * cosf(6.28318530718f * u2);
+        const float v0 = 1.0f + c * x;
+        if (v0 <= 0.0f) continue;
+        const float v = v0 * v0 * v0;
+        if (logf(u3) < 0.5f * x * x + d - d * v + d * logf(v)) { g = d * v; break; }
+    }
+    return g * powf(u01(key), 1.0f / alpha);
+}
+
 // self_play.py:61-68 + 146-148: expand the pending leaf with its priors and apply its backups
 __device__ void consume_eval(const Eng &E, int g, WaveLds &L, const Tree &T, int eval_kind,
-                             const void *ev_a, const void *ev_v)
+                             const void *ev_a, const void *ev_v, int ply)
 {
     const int lane = XQ_LANE;
     const int node = E.leaf_node[g];
@@ -309,6 +335,18 @@ __device__ void consume_eval(const Eng &E, int g, WaveLds &L, const Tree &T, int
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d, 64);
         p0 = e0 / sum; p1 = e1 / sum;
+    }
+    if (E.noise_eps > 0.0 && node == 0) {
+        // P' = (1 - eps) P + eps * eta, eta ~ Dirichlet(alpha) over the root's children
+        const uint64_t base = E.noise_seed ^ mix64(((uint64_t)g << 20) ^ ((uint64_t)ply << 8));
+        float g0 = lane < n ? gamma_sample((float)E.noise_alpha, base + (uint64_t)lane * 1024u) : 0.f;
+        float g1 = lane + 64 < n ? gamma_sample((float)E.noise_alpha, base + (uint64_t)(lane + 64) * 1024u) : 0.f;
+        float gs_ = g0 + g1;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) gs_ += __shfl_xor(gs_, d, 64);
+        const float eps = (float)E.noise_eps;
+        p0 = (1.0f - eps) * p0 + eps * (g0 / gs_);
+        p1 = (1.0f - eps) * p1 + eps * (g1 / gs_);
     }
     const int first = (int)E.n_nodes[g];
     if (first + n <= E.ncap) {
@@ -422,7 +460,7 @@ __global__ __launch_bounds__(64) void k_search_round(Eng E, int round, int batch
         }
         mem_fence_wave();
     } else {
-        consume_eval(E, g, L, T, eval_kind, ev_a, ev_v);
+        consume_eval(E, g, L, T, eval_kind, ev_a, ev_v, gs.n_plies);
     }
 
     unpack_to_lds(E.board + (size_t)g * 12, L.root_bd);
@@ -530,9 +568,10 @@ __global__ __launch_bounds__(64) void k_end_search(Eng E, int eval_kind, const v
 {
     __shared__ WaveLds L;
     const int g = blockIdx.x;
-    if (E.gs[g].done) return;
+    const GameS gs = load_gs(E.gs + g);
+    if (gs.done) return;
     const Tree T = tree_of(E, g);
-    consume_eval(E, g, L, T, eval_kind, ev_a, ev_v);
+    consume_eval(E, g, L, T, eval_kind, ev_a, ev_v, gs.n_plies);
 }
 
 // NumPy float64 add.reduce (pairwise, 8 partial sums; n <= 128)
@@ -920,6 +959,7 @@ struct xq_engine {
     hipStream_t stream = nullptr;
     std::vector<void *> allocs;
     double *pow_table_dev = nullptr;
+    int pow_cap = 0;
     int *active_dev = nullptr;
     int8_t *stage_boards = nullptr;      // [G][90] staging for set_roots / read_leaves
     int32_t *stage_state = nullptr;      // [G][XQ_STATE_WORDS]
@@ -1010,11 +1050,17 @@ extern "C" int xq_engine_set_pow_table(xq_engine *e, const double *t, int n)
 {
     if (!e) return fail(XQ_E_INVALID, "null engine");
     if (!t || n <= 0) { e->E.pow_table = nullptr; e->E.pow_n = 0; return 0; }
-    double *p = nullptr;
-    if (dalloc(e, p, (size_t)n)) return fail(XQ_E_HIP, "hipMalloc failed");
-    HIPCHK(hipMemcpyAsync(p, t, (size_t)n * 8, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipSetDevice(e->cfg.device));
+    if (n > e->pow_cap) {                    // one persistent buffer, regrown only when needed
+        double *p = nullptr;
+        const int cap = n > e->E.sims + 1 ? n : e->E.sims + 1;
+        if (dalloc(e, p, (size_t)cap)) return fail(XQ_E_HIP, "hipMalloc failed");
+        e->pow_table_dev = p;
+        e->pow_cap = cap;
+    }
+    HIPCHK(hipMemcpyAsync(e->pow_table_dev, t, (size_t)n * 8, hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
-    e->E.pow_table = p; e->E.pow_n = n;
+    e->E.pow_table = e->pow_table_dev; e->E.pow_n = n;
     return 0;
 }
 
@@ -1061,6 +1107,37 @@ extern "C" int xq_engine_new_games(xq_engine *e, const uint32_t *seeds)
     HIPCHK(hipStreamSynchronize(e->stream));          // u is a local: copy must finish
     hipLaunchKernelGGL(k_new_games, dim3(e->E.G), dim3(64), 0, e->stream, e->E);
     HIPCHK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int xq_engine_set_temperature(xq_engine *e, double temperature, const double *table, int n)
+{
+    if (!e) return fail(XQ_E_INVALID, "null engine");
+    e->E.temperature = temperature;
+    e->cfg.temperature = temperature;
+    return xq_engine_set_pow_table(e, table, n);
+}
+
+extern "C" int xq_engine_set_root_noise(xq_engine *e, double alpha, double epsilon, uint64_t seed)
+{
+    if (!e) return fail(XQ_E_INVALID, "null engine");
+    if (epsilon < 0.0 || epsilon > 1.0 || (epsilon > 0.0 && alpha <= 0.0)) return fail(XQ_E_INVALID, "bad alpha / epsilon");
+    e->E.noise_alpha = alpha; e->E.noise_eps = epsilon; e->E.noise_seed = seed;
+    return 0;
+}
+
+extern "C" int xq_engine_read_root_priors(xq_engine *e, float *priors /*[G][128]*/)
+{
+    if (!e || !priors) return fail(XQ_E_INVALID, "null argument");
+    HIPCHK(hipSetDevice(e->cfg.device));
+    const size_t G = (size_t)e->E.G, NC = (size_t)e->E.ncap;
+    std::vector<float> P(G * (MAXM + 1));
+    std::vector<uint8_t> nc(G);
+    HIPCHK(hipMemcpy2DAsync(P.data(), (MAXM + 1) * 4, e->E.nP, NC * 4, (MAXM + 1) * 4, G, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpy2DAsync(nc.data(), 1, e->E.nNc, NC, 1, G, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    for (size_t g = 0; g < G; g++)
+        for (int j = 0; j < MAXM; j++) priors[g * MAXM + j] = j < nc[g] ? P[g * (MAXM + 1) + 1 + j] : 0.f;
     return 0;
 }
 

@@ -136,11 +136,17 @@ class GameBatch:
             n = int(self.s_n[g, i])
             moves = [decode_move(m) for m in self.s_moves[g, i, :n]]
             counts = self.s_counts[g, i, :n].astype(np.int64)
-            if self.temperature < 0.01:                       # self_play.py:224-227
+            temp = self.temperature
+            pt = getattr(self, "ply_temperature", None)
+            if pt:                                            # per-ply schedule (extension)
+                ply = 2 * i if getattr(self, "opponent_mode", False) else i
+                if ply < len(pt):
+                    temp = pt[ply]
+            if temp < 0.01:                                   # self_play.py:224-227
                 probs = np.zeros(n)
                 probs[np.argmax(counts)] = 1
             else:                                             # self_play.py:230-231
-                c = counts ** (1.0 / self.temperature)
+                c = counts ** (1.0 / temp)
                 probs = c / c.sum()
             out.append((self.s_board[g, i].reshape(10, 9).copy(), {m: p for m, p in zip(moves, probs)},
                         float(self.s_z[g, i])))
@@ -232,16 +238,41 @@ class SelfPlayEngine:
         return int(n[0])
 
     # ---- whole games ------------------------------------------------------------------------
-    def play(self, evaluator, seeds, opponent_evaluator=None, uniforms=None, check_every=8, read=True):
+    def set_temperature(self, temperature):
+        """Per-ply temperature (extension; the reference uses one temperature per game)."""
+        tab = None
+        if temperature >= 0.01 and temperature != 1.0:
+            tab = np.ascontiguousarray(np.arange(self.sims + 1, dtype=np.int64) ** (1.0 / temperature), dtype=np.float64)
+        _lib.check(self.L.xq_engine_set_temperature(self.h, float(temperature), _lib.ptr(tab), 0 if tab is None else len(tab)))
+
+    def set_root_noise(self, alpha, epsilon, seed=0):
+        """Dirichlet root noise (extension, BASELINE C5): root priors (1-eps) P + eps Dir(alpha)."""
+        _lib.check(self.L.xq_engine_set_root_noise(self.h, float(alpha), float(epsilon), int(seed)))
+
+    def root_priors(self):
+        p = np.zeros((self.n_games, _lib.MAX_MOVES), np.float32)
+        _lib.check(self.L.xq_engine_read_root_priors(self.h, _lib.ptr(p)))
+        return p
+
+    def play(self, evaluator, seeds, opponent_evaluator=None, uniforms=None, check_every=8, read=True,
+             temperature_schedule=None):
         """Play G games to the end (self_play_game for every game).  `seeds[g]` seeds game g's
-        MT19937 stream like np.random.seed; `uniforms` overrides the streams."""
+        MT19937 stream like np.random.seed; `uniforms` overrides the streams.
+        `temperature_schedule(ply) -> T` (extension) overrides the constant temperature per ply."""
         evaluator.bind(self)
         if opponent_evaluator is not None:
             opponent_evaluator.bind(self)
         self.new_games(seeds)
         if uniforms is not None:
             self.set_uniforms(uniforms)
+        self.ply_temperature = []
+        cur_t = None
         for ply in range(min(self.max_moves, _lib.MAX_PLIES)):
+            t = self.temperature if temperature_schedule is None else float(temperature_schedule(ply))
+            if temperature_schedule is not None and t != cur_t:
+                self.set_temperature(t)
+                cur_t = t
+            self.ply_temperature.append(t)
             ev = evaluator if (ply % 2 == 0 or opponent_evaluator is None) else opponent_evaluator   # self_play.py:211
             self.search(ev)
             _lib.check(self.L.xq_engine_play_move(self.h))
@@ -253,6 +284,8 @@ class SelfPlayEngine:
     def read_results(self):
         G, P, M = self.n_games, _lib.MAX_PLIES, _lib.MAX_MOVES
         b = GameBatch(G, self.temperature)
+        b.ply_temperature = list(getattr(self, "ply_temperature", []))
+        b.opponent_mode = self.opponent_mode
         for name in ("winner", "reason", "reason_side", "reason_count", "n_plies", "n_samples", "error"):
             setattr(b, name, np.zeros(G, np.int32))
         _lib.check(self.L.xq_engine_read_games(self.h, _lib.ptr(b.winner), _lib.ptr(b.reason), _lib.ptr(b.reason_side),

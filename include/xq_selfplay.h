@@ -132,6 +132,14 @@ int  xq_engine_set_pow_table(xq_engine *e, const double *table_host, int n);
  * double per ply from it). */
 int  xq_engine_new_games(xq_engine *e, const uint32_t *seeds_host);
 
+/* ---- opt-in search extensions with NO counterpart in the reference (BASELINE config C5) ----
+ * per-ply temperature (call between plies; table as in xq_engine_set_pow_table) */
+int  xq_engine_set_temperature(xq_engine *e, double temperature, const double *table_host, int n);
+/* Dirichlet root noise: root priors become (1-eps) P + eps Dir(alpha); eps = 0 (default) disables */
+int  xq_engine_set_root_noise(xq_engine *e, double alpha, double epsilon, uint64_t seed);
+/* priors stored on the root's children after the root was expanded, [G][128] */
+int  xq_engine_read_root_priors(xq_engine *e, float *priors_host);
+
 /* Replace the per-game uniform streams: uniforms_host[g][ply] is the double np.random.choice
  * consumes at that ply (self_play.py:242).  Lets the host mirror draw from NumPy's GLOBAL stream
  * exactly as the reference does (Appendix A14).  Call after xq_engine_new_games. */
