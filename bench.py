@@ -135,6 +135,8 @@ def main():
                     help="profiling aid only: stop every step after this many plies (the JSON line is then NOT a benchmark)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--net-chunk", type=int, default=0, help="rows per network launch (0 = all games at once)")
+    ap.add_argument("--root-noise", default="", help="extension (BASELINE C5): 'alpha,eps' Dirichlet root noise, e.g. 0.3,0.25")
+    ap.add_argument("--temp-cutoff", type=int, default=0, help="extension (C5): temperature 1.0 before this ply, ~0 after")
     ap.add_argument("--conv-variant", type=int, default=0, help="diagnostic: 1 = 2 boards/WG, 2 = 4 boards/WG (0 = library default)")
     args = ap.parse_args()
 
@@ -183,7 +185,8 @@ def main():
         ev.evaluate = timed_eval if timed else orig_eval
         ev.inet.tower_events = tower_events if timed else None
         seeds = xd.game_seeds(base_seed, G * world, rank, world)
-        eng.play(ev, seeds, read=False)
+        sched = (lambda ply: 1.0 if ply < args.temp_cutoff else 0.001) if args.temp_cutoff > 0 else None
+        eng.play(ev, seeds, read=False, temperature_schedule=sched)
         eng.pack_samples(records.data_ptr())
         if world > 1:
             xd.all_gather_records(records)
@@ -196,6 +199,9 @@ def main():
     eng = SelfPlayEngine(G, sims=S, planes_format=ev.planes_format, device=dev, stream=stream)
     if args.profile_plies > 0:
         eng.max_moves = args.profile_plies
+    if args.root_noise:
+        a_, e_ = (float(v) for v in args.root_noise.split(","))
+        eng.set_root_noise(a_, e_, seed=12345 + rank)
     for w in range(args.warmup):
         saved = eng.max_moves
         if args.warmup_plies > 0:
@@ -236,8 +242,12 @@ def main():
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic" if not args.profile_plies else
             "synthetic; PROFILING RUN truncated to %d plies per step - not a benchmark" % args.profile_plies,
-            "config": {"workload": "BASELINE configs[2]: %d concurrent games/GPU, %d sims, %d-block ResNet %s, "
-                                   "random-init weights, start positions, seeds base+g" % (G, S, args.blocks, args.dtype),
+            "config": {"workload": "%s%d concurrent games/GPU, %d sims, %d-block ResNet %s, "
+                                   "random-init weights, start positions, seeds base+g%s" % (
+                                       "BASELINE configs[2]: " if (G, S, args.blocks) == (16384, 50, 6) else "",
+                                       G, S, args.blocks, args.dtype,
+                                       (", Dirichlet root noise %s, temperature 1 -> 0 at ply %d (extensions, no reference oracle)"
+                                        % (args.root_noise, args.temp_cutoff)) if (args.root_noise or args.temp_cutoff) else ""),
                        "games_per_gpu": G, "sims": S, "blocks": args.blocks, "max_moves": 70,
                        "parallelism": "games sharded x%d, all-gather of samples at step end" % world},
             "roofline": {"bound": "mfma", "achieved": conv_tflops, "peak": MFMA_PEAK_BF16_TFLOPS, "unit": "TFLOP/s",

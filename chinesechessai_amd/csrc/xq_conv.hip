@@ -99,7 +99,8 @@ __global__ __launch_bounds__(NB * 128, 2) void k_conv3x3_b(const uint16_t *__res
     };
     stamp(0);
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: LDS-DMA bases stay in SGPRs
     const int wb_ = wave >> 1, hc = wave & 1;            // board within the workgroup, channel half
     const int board = blockIdx.x * NB + wb_;
     const bool board_ok = board < G;
@@ -110,15 +111,22 @@ __global__ __launch_bounds__(NB * 128, 2) void k_conv3x3_b(const uint16_t *__res
 
     constexpr int WINSTR = (COUT * WNCH + NT - 1) / NT;  // DMA instructions per wave per stage
     constexpr bool WEXACT = (WINSTR * NT == COUT * WNCH);
+    // per-lane source offsets of the weight DMA pieces are loop-invariant: a piece is then
+    // "uniform stage base + 32-bit lane offset", no 64-bit address arithmetic per piece
+    int wsrc[WINSTR];
+#pragma unroll
+    for (int j = 0; j < WINSTR; j++) {
+        const int q = (wave * WINSTR + j) * 64 + lane, row = q / WNCH, cp = q % WNCH;
+        wsrc[j] = row * ROWB + ((cp ^ wswz(row)) * 16);
+    }
     auto stage_weights = [&](int st, int buf) {
         const int tap = st / SPT, kb = (st % SPT) * KSL;
         const uint8_t *src = reinterpret_cast<const uint8_t *>(w) + ((size_t)tap * COUT * CIN + kb) * 2;
 #pragma unroll
         for (int j = 0; j < WINSTR; j++) {
             const int q0 = (wave * WINSTR + j) * 64;
-            const int q = q0 + lane, row = q / WNCH, cp = q % WNCH;
-            if (WEXACT || q < COUT * WNCH)
-                dma16(src + (size_t)row * ROWB + ((cp ^ wswz(row)) * 16), wbuf + buf * WBUF_BYTES + q0 * 16);
+            if (WEXACT || q0 + lane < COUT * WNCH)
+                dma16(src + wsrc[j], wbuf + buf * WBUF_BYTES + q0 * 16);
         }
     };
     if (tid < 16) reinterpret_cast<uint4 *>(zrow)[tid] = make_uint4(0, 0, 0, 0);
