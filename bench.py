@@ -152,7 +152,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    # XQ_BENCH_FORCE_DIST=1 rehearses the RCCL code path (init, all-gather, barrier, all-reduce)
+    # with a single rank under torch.distributed.run
+    use_dist = world > 1 or (os.environ.get("XQ_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ)
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -188,11 +191,11 @@ def main():
         sched = (lambda ply: 1.0 if ply < args.temp_cutoff else 0.001) if args.temp_cutoff > 0 else None
         eng.play(ev, seeds, read=False, temperature_schedule=sched)
         eng.pack_samples(records.data_ptr())
-        if world > 1:
+        if use_dist:
             xd.all_gather_records(records)
 
     def sync():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -220,7 +223,7 @@ def main():
     n_fw = len(fw_events)
     outcomes = eng.read_game_outcomes()
     t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
 
@@ -275,7 +278,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.blocks, S)
         print(json.dumps(out))
     eng.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
