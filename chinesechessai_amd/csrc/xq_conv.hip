@@ -64,6 +64,19 @@ __device__ __forceinline__ void dma16(const void *gsrc, void *lds_wave_base)
 //   variant B: NB 2, KSLP 64  -> 256 threads, 79.6 KB LDS, 2 workgroups per CU, 18 stages
 //   variant C: NB 4, KSLP 128 -> 512 threads, 158.5 KB LDS, 1 workgroup per CU, 9 stages (half the
 //              weight re-streaming and half the barriers / DMA pieces of B)
+// LDS-DMA through a buffer resource: address = SGPR resource + per-lane 32-bit voffset + scalar
+// soffset, i.e. no per-piece 64-bit VALU address arithmetic.
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ rsrc_t make_rsrc(const void *base, int bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), /*stride*/ 0, bytes, /*flags*/ 0x00020000);
+}
+__device__ __forceinline__ void dma16_buf(rsrc_t rsrc, int voffset, int soffset, void *lds_wave_base)
+{
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)lds_wave_base, 16, voffset,
+                                             soffset, 0, 0);
+}
+
 template <int CIN, int NB, int KSLP, bool STAMP = false, int ABLATE = 0>
 __global__ __launch_bounds__(NB * 128, 2) void k_conv3x3_b(const uint16_t *__restrict__ x, const uint16_t *__restrict__ w,
                                                       const float *__restrict__ bias, const uint16_t *__restrict__ res,
@@ -119,14 +132,15 @@ __global__ __launch_bounds__(NB * 128, 2) void k_conv3x3_b(const uint16_t *__res
         const int q = (wave * WINSTR + j) * 64 + lane, row = q / WNCH, cp = q % WNCH;
         wsrc[j] = row * ROWB + ((cp ^ wswz(row)) * 16);
     }
+    const rsrc_t wrsrc = make_rsrc(w, 9 * COUT * CIN * 2);
     auto stage_weights = [&](int st, int buf) {
         const int tap = st / SPT, kb = (st % SPT) * KSL;
-        const uint8_t *src = reinterpret_cast<const uint8_t *>(w) + ((size_t)tap * COUT * CIN + kb) * 2;
+        const int soff = (tap * COUT * CIN + kb) * 2;                    // scalar stage base
 #pragma unroll
         for (int j = 0; j < WINSTR; j++) {
             const int q0 = (wave * WINSTR + j) * 64;
             if (WEXACT || q0 + lane < COUT * WNCH)
-                dma16(src + wsrc[j], wbuf + buf * WBUF_BYTES + q0 * 16);
+                dma16_buf(wrsrc, wsrc[j], soff, wbuf + buf * WBUF_BYTES + q0 * 16);
         }
     };
     if (tid < 16) reinterpret_cast<uint4 *>(zrow)[tid] = make_uint4(0, 0, 0, 0);
