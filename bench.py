@@ -137,6 +137,7 @@ def main():
     ap.add_argument("--net-chunk", type=int, default=0, help="rows per network launch (0 = all games at once)")
     ap.add_argument("--root-noise", default="", help="extension (BASELINE C5): 'alpha,eps' Dirichlet root noise, e.g. 0.3,0.25")
     ap.add_argument("--temp-cutoff", type=int, default=0, help="extension (C5): temperature 1.0 before this ply, ~0 after")
+    ap.add_argument("--search-occ", type=int, default=0, help="diagnostic: k_search_round waves/SIMD variant (3, 5, 6, 8)")
     ap.add_argument("--conv-variant", type=int, default=0, help="diagnostic: 1 = 2 boards/WG, 2 = 4 boards/WG (0 = library default)")
     args = ap.parse_args()
 
@@ -149,6 +150,8 @@ def main():
 
     if args.conv_variant:
         _lib.lib().xq_conv3x3_set_variant(args.conv_variant)
+    if args.search_occ:
+        _lib.lib().xq_engine_set_search_occupancy(args.search_occ)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

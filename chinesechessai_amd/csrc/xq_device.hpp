@@ -22,7 +22,15 @@ enum : int { R_NONE = 0, R_KING_CAPTURED = 1, R_CHECKMATE = 2, R_REPETITION = 3,
 
 #define XQ_LANE ((int)(threadIdx.x & 63))
 
-__device__ __forceinline__ void wave_sync() { __syncthreads(); }   // block == one wave
+// Intra-wave LDS hand-off between lanes.  A wave's LDS instructions execute in issue order, so
+// no s_barrier is needed: the fence only pins the compiler's ordering.  (Workgroups may hold
+// several independent waves = games; they never exchange data.)
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 

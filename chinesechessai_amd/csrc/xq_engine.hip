@@ -444,9 +444,16 @@ __device__ void record_leaf(const Eng &E, int g, WaveLds &L, const int8_t *bd, i
     if (planes) write_planes(bd, side, planes, fmt, g);
 }
 
-__global__ __launch_bounds__(64) void k_search_round(Eng E, int round, int batch_count, int eval_kind,
-                                                     const void *ev_a, const void *ev_v, void *planes, int fmt)
+// OCC = minimum waves per SIMD requested from the register allocator.  The kernel is a chain of
+// dependent global loads (tree walk) with ~1.6 k VALU per wave, i.e. latency-bound: occupancy is
+// the lever (PMC: 62 % of wave cycles in s_waitcnt at 3 waves/SIMD).
+template <int OCC>
+__global__ __launch_bounds__(64, OCC) void k_search_round(Eng E, int round, int batch_count, int eval_kind,
+                                                          const void *ev_a, const void *ev_v, void *planes, int fmt)
 {
+    // one wave = one game = one workgroup (packing 4 games into a 256-thread workgroup was
+    // measured 20-40 % slower at the same register budget: a workgroup retires only with its
+    // slowest game)
     __shared__ WaveLds L;
     const int g = blockIdx.x, lane = XQ_LANE;
     const GameS gs = load_gs(E.gs + g);
@@ -1192,6 +1199,10 @@ static int drain_events(xq_engine *e)
     return 0;
 }
 
+static int g_search_occ = 5;      // 96 VGPRs, 5 waves/SIMD: fastest of {3, 5, 6, 8} (0.101 vs 0.119 ms at 3)
+// diagnostic only (not part of the public ABI): register budget variant of k_search_round
+extern "C" void xq_engine_set_search_occupancy(int waves_per_simd) { g_search_occ = waves_per_simd; }
+
 extern "C" int xq_engine_search_round(xq_engine *e, int round, int eval_kind, const void *ev_a, const void *ev_v,
                                       void *planes)
 {
@@ -1209,8 +1220,14 @@ extern "C" int xq_engine_search_round(xq_engine *e, int round, int eval_kind, co
         ev = next_events(e->ev_search, e->ev_search_used);
         if (ev) HIPCHK(hipEventRecord(ev->first, e->stream));
     }
-    hipLaunchKernelGGL(k_search_round, dim3(e->E.G), dim3(64), 0, e->stream, e->E, round, batch, eval_kind, ev_a, ev_v,
-                       planes, planes ? e->cfg.planes_format : XQ_PLANES_NONE);
+    const int fmt = planes ? e->cfg.planes_format : XQ_PLANES_NONE;
+    switch (g_search_occ) {
+    case 3: hipLaunchKernelGGL(k_search_round<3>, dim3(e->E.G), dim3(64), 0, e->stream, e->E, round, batch, eval_kind, ev_a, ev_v, planes, fmt); break;
+    case 5: hipLaunchKernelGGL(k_search_round<5>, dim3(e->E.G), dim3(64), 0, e->stream, e->E, round, batch, eval_kind, ev_a, ev_v, planes, fmt); break;
+    case 6: hipLaunchKernelGGL(k_search_round<6>, dim3(e->E.G), dim3(64), 0, e->stream, e->E, round, batch, eval_kind, ev_a, ev_v, planes, fmt); break;
+    case 8: hipLaunchKernelGGL(k_search_round<8>, dim3(e->E.G), dim3(64), 0, e->stream, e->E, round, batch, eval_kind, ev_a, ev_v, planes, fmt); break;
+    default: hipLaunchKernelGGL(k_search_round<5>, dim3(e->E.G), dim3(64), 0, e->stream, e->E, round, batch, eval_kind, ev_a, ev_v, planes, fmt); break;
+    }
     HIPCHK(hipGetLastError());
     if (ev) HIPCHK(hipEventRecord(ev->second, e->stream));
     return 0;
