@@ -189,18 +189,16 @@ class ChineseChess:
         """chess_env.py:607-612"""
         return self.no_capture_count >= 100
 
+    _GLYPHS = "·帅士相马车炮兵卒炮车马象士将"      # index = piece code (negative codes index from the end)
+
     def render(self):
-        """chess_env.py:408-429"""
-        names = {0: '·', 1: '帅', 2: '士', 3: '相', 4: '马', 5: '车', 6: '炮', 7: '兵',
-                 -1: '将', -2: '士', -3: '象', -4: '马', -5: '车', -6: '炮', -7: '卒'}
-        print("\n  ", end="")
-        for i in range(BOARD_WIDTH):
-            print(f"{i} ", end="")
-        print()
+        """Text dump of the position (chess_env.py:408-429): header row, one line per rank, side
+        to move and ply counter."""
+        lines = ["", "  " + "".join(f"{c} " for c in range(BOARD_WIDTH))]
         for r in range(BOARD_SIZE):
-            print(f"{r} ", end="")
-            for c in range(BOARD_WIDTH):
-                print(names[int(self.board[r, c])], end=" ")
-            print()
-        print(f"\n当前: {'红方' if self.current_player == 1 else '黑方'}")
-        print(f"步数: {self.move_count}")
+            cells = " ".join(self._GLYPHS[int(p)] for p in self.board[r])
+            lines.append(f"{r} {cells} ")
+        lines.append("")
+        lines.append("当前: " + ("红方" if self.current_player == 1 else "黑方"))
+        lines.append(f"步数: {self.move_count}")
+        print("\n".join(lines))

@@ -1,32 +1,29 @@
-"""Constants of the reference's config.py that the self-play hot path reads
-(config.py:9-10,48,62-74).  Trainer policy, display and path settings are out of scope."""
-SELF_PLAY_GAMES = 100
-MAX_MOVES = 70                  # config.py:9 (the rules engine hard-codes the same 70, chess_env.py:400)
-MCTS_SIMULATIONS = 50           # config.py:10
-NUM_WORKERS = 4                 # config.py:48 (accepted and ignored: one process per GPU, G games in lock-step)
+"""The handful of reference constants the self-play hot path reads (config.py:9-10,48,62-74 of the
+reference).  Trainer policy, display and path settings are out of scope."""
+
+# search / game limits
+MCTS_SIMULATIONS = 50            # simulations per move (reference config.py:10)
+MAX_MOVES = 70                   # plies per game (config.py:9); make_move hard-codes the same cap (chess_env.py:400)
+LEAF_BATCH = 8                   # leaves evaluated together (self_play.py:101)
+C_PUCT = 1.5                     # exploration constant (self_play.py:40)
+SELF_PLAY_GAMES = 100            # games per collection round (config.py:8)
+NUM_WORKERS = 4                  # reference pool size (config.py:48); accepted and ignored here
 USE_MULTIPROCESSING = True
 
-BOARD_SIZE = 10                 # config.py:62-63
-BOARD_WIDTH = 9
+# board geometry and piece codes: +code red, -code black (config.py:62-74)
+BOARD_SIZE, BOARD_WIDTH = 10, 9
+_KINDS = ("KING", "ADVISOR", "BISHOP", "KNIGHT", "ROOK", "CANNON", "PAWN")
+PIECES = {"EMPTY": 0}
+for _code, _kind in enumerate(_KINDS, start=1):
+    PIECES["R_" + _kind] = _code
+    PIECES["B_" + _kind] = -_code
 
-PIECES = {                      # config.py:66-74
-    'EMPTY': 0,
-    'R_KING': 1, 'R_ADVISOR': 2, 'R_BISHOP': 3, 'R_KNIGHT': 4, 'R_ROOK': 5, 'R_CANNON': 6, 'R_PAWN': 7,
-    'B_KING': -1, 'B_ADVISOR': -2, 'B_BISHOP': -3, 'B_KNIGHT': -4, 'B_ROOK': -5, 'B_CANNON': -6, 'B_PAWN': -7,
-}
-
-LEAF_BATCH = 8                  # self_play.py:101
-C_PUCT = 1.5                    # self_play.py:40
+_SIM_SCHEDULE = ((1000, 30), (3000, 35), (8000, 60), (15000, 100))
 
 
 def get_dynamic_mcts_simulations(total_games):
-    """config.py:13-28"""
-    if total_games < 1000:
-        return 30
-    elif total_games < 3000:
-        return 35
-    elif total_games < 8000:
-        return 60
-    elif total_games < 15000:
-        return 100
+    """Simulation count by games trained so far (config.py:13-28): 30 / 35 / 60 / 100 / 150."""
+    for limit, sims in _SIM_SCHEDULE:
+        if total_games < limit:
+            return sims
     return 150
