@@ -51,16 +51,18 @@ def tree_bytes_per_descent(b=33.3, lvl=0.86):
     return 64 + 16 * b * lvl + 2 * b + 48 + 2880 + (2 * b + 2) + 2 * b + 22 * b + 24 * (lvl + 1)
 
 
-def tree_traffic(G, S, blocks):
-    """HBM bytes per k_search_round launch from the committed PMC passes (profiles/): FETCH_SIZE +
-    WRITE_SIZE (KB) of separate rocprofv3 --pmc runs of this same workload; None for other configs."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_tree_kernels.json")
+def pmc_traffic(kernel, G, S, blocks, fetch_factor=1.0):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/r01d_pmc_kernels.json:
+    separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same workload, KB per launch).
+    fetch_factor = 2 for kernels that read with 16 B/lane coalesced accesses (gfx950 FETCH_SIZE
+    correction, MI355X_MICROARCH.md); None for configs that were not profiled."""
+    path = os.path.join(ROOT, "profiles", "r01d_pmc_kernels.json")
     if not (G == 16384 and S == 50 and blocks == 6 and os.path.exists(path)):
         return None
-    k = json.load(open(path))["kernels"].get("k_search_round")
+    k = json.load(open(path))["kernels"].get(kernel)
     if not k:
         return None
-    return (k["FETCH_SIZE_KB_mean_per_launch"] + k["WRITE_SIZE_KB_mean_per_launch"]) * 1024.0
+    return (fetch_factor * k["FETCH_SIZE_KB_mean_per_launch"] + k["WRITE_SIZE_KB_mean_per_launch"]) * 1024.0
 
 
 # ------------------------------------------------------------------------------------------
@@ -265,7 +267,8 @@ def main():
                        "games_per_gpu": G, "sims": S, "blocks": args.blocks, "max_moves": 70,
                        "parallelism": "games sharded x%d, all-gather of samples at step end" % world},
             "roofline": {"bound": "mfma", "achieved": conv_tflops, "peak": MFMA_PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": conv_tflops / MFMA_PEAK_BF16_TFLOPS, "traffic": None,
+                         "frac": conv_tflops / MFMA_PEAK_BF16_TFLOPS,
+                         "traffic": pmc_traffic("k_conv3x3_b<128>", G, S, args.blocks, fetch_factor=2.0),
                          "kernel": "k_conv3x3_b<128> (hand-written fused conv3x3+bias+residual+ReLU; %d launches of %d "
                                    "boards, %.4f ms avg; %.0f%% of the step)" % (
                                        n_conv, G, conv_ms / max(n_conv, 1), 100.0 * conv_ms / (dt * 1e3)),
@@ -276,7 +279,7 @@ def main():
                                  n_fw, rows, fw_ms / max(n_fw, 1)),
                              "flops_per_launch": fl * rows},
             "roofline_tree": {"bound": "hbm", "achieved": tree_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                              "frac": tree_gbs / HBM_PEAK_GBS, "traffic": tree_traffic(G, S, args.blocks),
+                              "frac": tree_gbs / HBM_PEAK_GBS, "traffic": pmc_traffic("k_search_round", G, S, args.blocks),
                               "kernel": "k_search_round (%d launches, %.3f ms avg)" % (
                                   prof["search_launches"], prof["search_ms"] / max(prof["search_launches"], 1)),
                               "bytes_per_launch": bpd * G},
