@@ -1199,7 +1199,8 @@ static int drain_events(xq_engine *e)
     return 0;
 }
 
-static int g_search_occ = 5;      // 96 VGPRs, 5 waves/SIMD: fastest of {3, 5, 6, 8} (0.101 vs 0.119 ms at 3)
+static int g_search_occ = 4;      // 128 VGPRs, 4 waves/SIMD: fastest of {3, 4, 5, 6, 8}: 0.097 ms (3: 0.118; 5: 0.101 with
+                                  // 56 B/lane of scratch that also adds 46 MB of HBM writes per launch)
 // diagnostic only (not part of the public ABI): register budget variant of k_search_round
 extern "C" void xq_engine_set_search_occupancy(int waves_per_simd) { g_search_occ = waves_per_simd; }
 
@@ -1223,10 +1224,11 @@ extern "C" int xq_engine_search_round(xq_engine *e, int round, int eval_kind, co
     const int fmt = planes ? e->cfg.planes_format : XQ_PLANES_NONE;
     switch (g_search_occ) {
     case 3: hipLaunchKernelGGL(k_search_round<3>, dim3(e->E.G), dim3(64), 0, e->stream, e->E, round, batch, eval_kind, ev_a, ev_v, planes, fmt); break;
+    case 4: hipLaunchKernelGGL(k_search_round<4>, dim3(e->E.G), dim3(64), 0, e->stream, e->E, round, batch, eval_kind, ev_a, ev_v, planes, fmt); break;
     case 5: hipLaunchKernelGGL(k_search_round<5>, dim3(e->E.G), dim3(64), 0, e->stream, e->E, round, batch, eval_kind, ev_a, ev_v, planes, fmt); break;
     case 6: hipLaunchKernelGGL(k_search_round<6>, dim3(e->E.G), dim3(64), 0, e->stream, e->E, round, batch, eval_kind, ev_a, ev_v, planes, fmt); break;
     case 8: hipLaunchKernelGGL(k_search_round<8>, dim3(e->E.G), dim3(64), 0, e->stream, e->E, round, batch, eval_kind, ev_a, ev_v, planes, fmt); break;
-    default: hipLaunchKernelGGL(k_search_round<5>, dim3(e->E.G), dim3(64), 0, e->stream, e->E, round, batch, eval_kind, ev_a, ev_v, planes, fmt); break;
+    default: hipLaunchKernelGGL(k_search_round<4>, dim3(e->E.G), dim3(64), 0, e->stream, e->E, round, batch, eval_kind, ev_a, ev_v, planes, fmt); break;
     }
     HIPCHK(hipGetLastError());
     if (ev) HIPCHK(hipEventRecord(ev->second, e->stream));
