@@ -140,6 +140,9 @@ def main():
     ap.add_argument("--root-noise", default="", help="extension (BASELINE C5): 'alpha,eps' Dirichlet root noise, e.g. 0.3,0.25")
     ap.add_argument("--temp-cutoff", type=int, default=0, help="extension (C5): temperature 1.0 before this ply, ~0 after")
     ap.add_argument("--search-occ", type=int, default=0, help="diagnostic: k_search_round waves/SIMD variant (3, 5, 6, 8)")
+    ap.add_argument("--policy-columns", default="all", choices=["all", "reachable"],
+                    help="'reachable' (opt-in): policy FC restricted to the 2.6k of 8,100 columns that can ever be a legal "
+                         "move (result-identical; the default keeps the reference's full head)")
     ap.add_argument("--conv-variant", type=int, default=0, help="diagnostic: 1 = 2 boards/WG, 2 = 4 boards/WG (0 = library default)")
     args = ap.parse_args()
 
@@ -172,7 +175,7 @@ def main():
     torch.manual_seed(0)                                   # same random-init weights on every rank
     net = ChessNet(num_blocks=args.blocks).eval().cuda()
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-    ev = TorchNetEvaluator(net, dtype=dtype, chunk=args.net_chunk or None)
+    ev = TorchNetEvaluator(net, dtype=dtype, chunk=args.net_chunk or None, policy_columns=args.policy_columns)
     stream = torch.cuda.current_stream().cuda_stream
     records = torch.zeros(G * _lib.MAX_PLIES * xd.RECORD_BYTES, dtype=torch.uint8, device="cuda")
 
@@ -244,6 +247,8 @@ def main():
         games = G * world * args.steps
         rows = G                                            # network rows per forward (one per game)
         fl = net_flops_per_row(args.blocks)
+        if args.policy_columns == "reachable":                 # only the computed FC rows count
+            fl -= 2 * 2880 * (8100 - ev.inet.n_policy)
         net_tflops = (fl * rows * n_fw) / (fw_ms * 1e-3) / 1e12 if fw_ms > 0 else 0.0
         bpd = tree_bytes_per_descent()
         tree_gbs = (bpd * G * prof["search_launches"]) / (prof["search_ms"] * 1e-3) / 1e9 if prof["search_ms"] > 0 else 0.0
@@ -262,6 +267,8 @@ def main():
                                    "random-init weights, start positions, seeds base+g%s" % (
                                        "BASELINE configs[2]: " if (G, S, args.blocks) == (16384, 50, 6) else "",
                                        G, S, args.blocks, args.dtype,
+                                       (", policy FC restricted to the %d reachable-move columns" % ev.inet.n_policy
+                                        if args.policy_columns == "reachable" else "") +
                                        (", Dirichlet root noise %s, temperature 1 -> 0 at ply %d (extensions, no reference oracle)"
                                         % (args.root_noise, args.temp_cutoff)) if (args.root_noise or args.temp_cutoff) else ""),
                        "games_per_gpu": G, "sims": S, "blocks": args.blocks, "max_moves": 70,

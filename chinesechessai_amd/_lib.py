@@ -98,6 +98,7 @@ _SIGNATURES = {
     "xq_engine_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "xq_engine_set_pow_table": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "xq_engine_new_games": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "xq_engine_set_logit_columns": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "xq_engine_set_temperature": (C.c_int, [C.c_void_p, C.c_double, C.c_void_p, C.c_int]),
     "xq_engine_set_root_noise": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_uint64]),
     "xq_engine_read_root_priors": (C.c_int, [C.c_void_p, C.c_void_p]),

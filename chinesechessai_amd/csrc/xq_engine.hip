@@ -81,6 +81,8 @@ struct Eng {
     // noise_eps == 0 keeps the reference behaviour
     double noise_alpha, noise_eps;
     uint64_t noise_seed;
+    // optional compact policy layout: logits rows hold only n_cols columns, col_map[move] = column
+    const int16_t *col_map; int n_cols;
 };
 
 struct __align__(16) WaveLds {
@@ -316,15 +318,18 @@ __device__ void consume_eval(const Eng &E, int g, WaveLds &L, const Tree &T, int
     } else {
         // neural_network.py:148-169: gather the legal logits, float32 softmax over them
         float x0 = -INFINITY, x1 = -INFINITY;
+        const int stride = E.col_map ? E.n_cols : XQ_POLICY_SIZE;
+        const int c0 = (E.col_map && lane < n) ? E.col_map[m0] : m0;
+        const int c1 = (E.col_map && lane + 64 < n) ? E.col_map[m1] : m1;
         if (eval_kind == XQ_EVAL_LOGITS_F32) {
-            const float *lg = reinterpret_cast<const float *>(ev_a) + (size_t)g * XQ_POLICY_SIZE;
-            if (lane < n) x0 = lg[m0];
-            if (lane + 64 < n) x1 = lg[m1];
+            const float *lg = reinterpret_cast<const float *>(ev_a) + (size_t)g * stride;
+            if (lane < n) x0 = lg[c0];
+            if (lane + 64 < n) x1 = lg[c1];
             v = (double)reinterpret_cast<const float *>(ev_v)[g];
         } else {
-            const uint16_t *lg = reinterpret_cast<const uint16_t *>(ev_a) + (size_t)g * XQ_POLICY_SIZE;
-            if (lane < n) x0 = bf16_to_f32(lg[m0]);
-            if (lane + 64 < n) x1 = bf16_to_f32(lg[m1]);
+            const uint16_t *lg = reinterpret_cast<const uint16_t *>(ev_a) + (size_t)g * stride;
+            if (lane < n) x0 = bf16_to_f32(lg[c0]);
+            if (lane + 64 < n) x1 = bf16_to_f32(lg[c1]);
             v = (double)bf16_to_f32(reinterpret_cast<const uint16_t *>(ev_v)[g]);
         }
         float mx = fmaxf(x0, x1);
@@ -1145,6 +1150,22 @@ extern "C" int xq_engine_read_root_priors(xq_engine *e, float *priors /*[G][128]
     HIPCHK(hipStreamSynchronize(e->stream));
     for (size_t g = 0; g < G; g++)
         for (int j = 0; j < MAXM; j++) priors[g * MAXM + j] = j < nc[g] ? P[g * (MAXM + 1) + 1 + j] : 0.f;
+    return 0;
+}
+
+extern "C" int xq_engine_set_logit_columns(xq_engine *e, const int16_t *map, int n_columns)
+{
+    if (!e) return fail(XQ_E_INVALID, "null engine");
+    if (!map || n_columns <= 0) { e->E.col_map = nullptr; e->E.n_cols = 0; return 0; }
+    if (n_columns > XQ_POLICY_SIZE) return fail(XQ_E_INVALID, "n_columns > 8100");
+    for (int i = 0; i < XQ_POLICY_SIZE; i++)
+        if (map[i] < -1 || map[i] >= n_columns) return fail(XQ_E_INVALID, "column map entry out of range");
+    HIPCHK(hipSetDevice(e->cfg.device));
+    int16_t *p = nullptr;
+    if (dalloc(e, p, (size_t)XQ_POLICY_SIZE)) return fail(XQ_E_HIP, "hipMalloc failed");
+    HIPCHK(hipMemcpyAsync(p, map, XQ_POLICY_SIZE * 2, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    e->E.col_map = p; e->E.n_cols = n_columns;
     return 0;
 }
 

@@ -79,7 +79,7 @@ class CallbackEvaluator:
 class TorchNetEvaluator:
     """InferenceNet under PyTorch-ROCm; the search kernel writes its input planes in place."""
 
-    def __init__(self, net, dtype=None, channels_last=True, chunk=None):
+    def __init__(self, net, dtype=None, channels_last=True, chunk=None, policy_columns="all"):
         import torch
         from .neural_network import InferenceNet
         self.torch = torch
@@ -94,7 +94,7 @@ class TorchNetEvaluator:
             raise ValueError("dtype must be bfloat16 or float32")
         self.channels_last = channels_last
         self.inet = net if isinstance(net, InferenceNet) else InferenceNet(
-            net, dtype=dtype, c_in=16 if channels_last else 15, device="cuda")
+            net, dtype=dtype, c_in=16 if channels_last else 15, device="cuda", policy_columns=policy_columns)
         self.chunk = chunk
         self.kind = _lib.EVAL_LOGITS_BF16 if dtype == torch.bfloat16 else _lib.EVAL_LOGITS_F32
 
@@ -107,7 +107,10 @@ class TorchNetEvaluator:
         else:
             self.storage = torch.zeros((G, 15, 10, 9), dtype=self.dtype, device="cuda")
             self.x = self.storage
-        self.logits = torch.empty((G, _lib.POLICY_SIZE), dtype=self.dtype, device="cuda")
+        self.logits = torch.empty((G, self.inet.n_policy), dtype=self.dtype, device="cuda")
+        cm = self.inet.column_map
+        _lib.check(engine.L.xq_engine_set_logit_columns(engine.h, _lib.ptr(cm) if cm is not None else None,
+                                                        self.inet.n_policy if cm is not None else 0))
         self.values = torch.empty((G,), dtype=self.dtype, device="cuda")
 
     def planes_ptr(self):

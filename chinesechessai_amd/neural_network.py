@@ -109,6 +109,47 @@ class ChessNet(nn.Module):
         return self.predict_batch([(board, current_player, legal_moves)])[0]
 
 
+def reachable_policy_columns():
+    """Policy-head columns (neural_network.py:160: idx = from*90 + to) that can ever be a legal
+    move: the union, over both sides and every source square, of the reference generators' targets
+    on an EMPTY board (chess_env.py:123-251; blockers only remove targets, cannon captures stay on
+    rook lines).  Returns (sorted column indices, int16 map move -> compact column or -1).
+    The other ~5,700 of the 8,100 logits are never read by the search (the engine gathers legal
+    moves only), so a policy FC restricted to these rows of its weight is result-identical."""
+    cols = set()
+    for r in range(10):
+        for c in range(9):
+            tg = set()
+            for k in range(9):                                   # rook / cannon lines
+                if k != c:
+                    tg.add((r, k))
+            for k in range(10):
+                if k != r:
+                    tg.add((k, c))
+            for dr, dc in ((2, 1), (2, -1), (-2, 1), (-2, -1), (1, 2), (-1, 2), (1, -2), (-1, -2)):   # knight
+                tg.add((r + dr, c + dc))
+            for side in (1, -1):
+                lo, hi = (7, 10) if side == 1 else (0, 3)
+                for dr, dc in ((0, 1), (0, -1), (1, 0), (-1, 0), (1, 1), (1, -1), (-1, 1), (-1, -1)):   # king, advisor
+                    if lo <= r + dr < hi and 3 <= c + dc < 6:
+                        tg.add((r + dr, c + dc))
+                for dr, dc in ((2, 2), (2, -2), (-2, 2), (-2, -2)):                                       # bishop
+                    nr = r + dr
+                    if (side == 1 and nr >= 5) or (side == -1 and nr < 4):
+                        tg.add((nr, c + dc))
+                tg.add((r - 1, c) if side == 1 else (r + 1, c))                                           # pawn
+                if (side == 1 and r < 5) or (side == -1 and r >= 5):
+                    tg.add((r, c - 1))
+                    tg.add((r, c + 1))
+            for tr, tc in tg:
+                if 0 <= tr < 10 and 0 <= tc < 9:
+                    cols.add((r * 9 + c) * 90 + tr * 9 + tc)
+    cols = sorted(cols)
+    cmap = np.full(8100, -1, dtype=np.int16)
+    cmap[cols] = np.arange(len(cols), dtype=np.int16)
+    return np.array(cols, dtype=np.int64), cmap
+
+
 def _fold_bn(conv, bn):
     """eval-mode BatchNorm folded into the preceding convolution (running stats, foldable per
     SURVEY.md §8a a12)."""
@@ -128,10 +169,11 @@ class InferenceNet(nn.Module):
     Output: (logits [G, 8100], values [G]) in `dtype`.
     """
 
-    def __init__(self, net, dtype=torch.bfloat16, c_in=16, device="cuda"):
+    def __init__(self, net, dtype=torch.bfloat16, c_in=16, device="cuda", policy_columns="all"):
         super().__init__()
         self.dtype = dtype
         self.c_in = c_in
+        self.policy_columns = policy_columns           # "all" (reference layout) | "reachable" (opt-in)
         convs = []
         w, b = _fold_bn(net.conv1, net.bn1)
         if c_in == 16:
@@ -173,8 +215,17 @@ class InferenceNet(nn.Module):
         # policy FC consumes the NHWC-flattened activation: permute its input columns once
         # from (c, h, w) order (neural_network.py:62) to (h, w, c)
         fcw = net.policy_fc.weight.detach().view(-1, 32, 90).permute(0, 2, 1).reshape(-1, 2880)
+        pfb = net.policy_fc.bias.detach()
+        self.column_map = None
+        if policy_columns == "reachable":
+            cols, cmap = reachable_policy_columns()
+            pad = (-len(cols)) % 8                          # keep rows 16-byte aligned in bf16
+            idx = torch.from_numpy(np.concatenate([cols, np.zeros(pad, np.int64)]))
+            fcw, pfb = fcw[idx], pfb[idx]
+            self.column_map = cmap
+        self.n_policy = fcw.shape[0]
         self.pfw = nn.Parameter(fcw.to(device=device, dtype=dtype).contiguous(), requires_grad=False)
-        self.pfb = nn.Parameter(net.policy_fc.bias.detach().to(device=device, dtype=dtype), requires_grad=False)
+        self.pfb = nn.Parameter(pfb.to(device=device, dtype=dtype), requires_grad=False)
         v1 = net.value_fc1.weight.detach().view(-1, 8, 90).permute(0, 2, 1).reshape(-1, 720)
         self.v1w = nn.Parameter(v1.to(device=device, dtype=dtype).contiguous(), requires_grad=False)
         self.v1b = nn.Parameter(net.value_fc1.bias.detach().to(device=device, dtype=dtype), requires_grad=False)

@@ -132,6 +132,11 @@ int  xq_engine_set_pow_table(xq_engine *e, const double *table_host, int n);
  * double per ply from it). */
 int  xq_engine_new_games(xq_engine *e, const uint32_t *seeds_host);
 
+/* Optional compact policy layout for XQ_EVAL_LOGITS_*: eval_a rows hold n_columns logits and
+ * map_host[move] (int16[8100]) gives the column of a move, -1 for moves that can never be legal.
+ * NULL restores the reference layout (8100 columns, column = move index; neural_network.py:160). */
+int  xq_engine_set_logit_columns(xq_engine *e, const int16_t *map_host, int n_columns);
+
 /* ---- opt-in search extensions with NO counterpart in the reference (BASELINE config C5) ----
  * per-ply temperature (call between plies; table as in xq_engine_set_pow_table) */
 int  xq_engine_set_temperature(xq_engine *e, double temperature, const double *table_host, int n);

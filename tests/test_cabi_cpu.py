@@ -136,3 +136,19 @@ def test_chessnet_state_dict_keys_and_shapes():
         xi = xi.contiguous(memory_format=torch.channels_last)
         p1, v1 = inet(xi)
         assert torch.allclose(p0, p1, atol=2e-5, rtol=1e-4) and torch.allclose(v0.reshape(-1), v1, atol=1e-5)
+
+
+def test_reachable_policy_columns_cover_every_legal_move(golden_dir):
+    """The opt-in compact policy head keeps exactly the columns a legal move can ever index: every
+    legal move of every golden position (5,194 plies of play + hand-built boards with pieces in
+    unusual places) must be in the set, and the map must be a bijection onto 0..n-1."""
+    import json
+    from chinesechessai_amd.neural_network import reachable_policy_columns
+    cols, cmap = reachable_policy_columns()
+    assert 2000 < len(cols) < 3000 and len(set(cols.tolist())) == len(cols)
+    assert (np.sort(cmap[cmap >= 0]) == np.arange(len(cols))).all() and (cmap[cols] == np.arange(len(cols))).all()
+    d = np.load(os.path.join(golden_dir, "rules_random.npz"))
+    for i in range(len(d["nlegal"])):
+        assert (cmap[d["legal"][i, :d["nlegal"][i]].astype(np.int64)] >= 0).all(), i
+    for c in json.load(open(os.path.join(golden_dir, "rules_edge.json"))):
+        assert all(cmap[m] >= 0 for m in c["legal"]), c["name"]

@@ -788,3 +788,47 @@ def test_search_extensions_are_opt_in_and_statistically_sound(L):
             assert bt.chosen[g, i] == bt.s_moves[g, i, int(np.argmax(bt.s_counts[g, i, :k]))], (g, i)
         pi = list(bt.game_data(g)[cut][1].values())
         assert sorted(pi)[-1] == 1.0 and sum(pi) == 1.0
+
+
+def test_reachable_policy_columns_give_the_same_priors(L, golden_dir):
+    """Opt-in compact policy head (2,294 of 8,100 columns) vs the full head on the network fixture
+    positions: identical legal-move priors up to the bf16 GEMM's shape-dependent rounding
+    (rtol 3e-2), same values; plus 20,000 random boards whose legal moves (HIP) all map to a column."""
+    import torch
+    from chinesechessai_amd import _lib
+    from chinesechessai_amd.engine import SelfPlayEngine, TorchNetEvaluator
+    from chinesechessai_amd.neural_network import ChessNet, reachable_policy_columns
+    d = np.load(os.path.join(golden_dir, "net.npz"))
+    n = len(d["players"])
+    torch.manual_seed(0)
+    net = ChessNet().cuda().eval()
+    pri = {}
+    for mode in ("all", "reachable"):
+        ev = TorchNetEvaluator(net, policy_columns=mode)
+        eng = SelfPlayEngine(n, sims=16, planes_format=ev.planes_format)
+        ev.bind(eng)
+        st = np.zeros((n, 10), np.int32)
+        st[:, 0] = d["players"]; st[:, 2] = 2
+        for i in range(n):
+            b = d["boards"][i].reshape(90)
+            st[i, 3] = int(np.argmax(b == 1)); st[i, 4] = int(np.argmax(b == -1))
+        eng.set_roots(d["boards"].reshape(n, 90), st)
+        eng.search(ev)                       # 2 rounds; the root is expanded with the network's priors
+        pri[mode] = eng.root_priors()
+        assert ev.logits.shape[1] == (8100 if mode == "all" else 2296)
+        eng.close()
+    for i in range(n):
+        k = d["nlegal"][i]
+        assert np.allclose(pri["all"][i, :k], pri["reachable"][i, :k], rtol=3e-2, atol=1e-5), i
+        assert abs(pri["reachable"][i, :k].sum() - 1) < 1e-3
+    cols, cmap = reachable_policy_columns()
+    rng = np.random.RandomState(99)
+    boards = np.zeros((20000, 90), np.int8)
+    for i in range(20000):
+        sq = rng.permutation(90)[:rng.randint(2, 30)]
+        boards[i, sq] = rng.choice([1, 2, 3, 4, 5, 6, 7, -1, -2, -3, -4, -5, -6, -7], size=len(sq))
+    player = rng.choice([1, -1], size=20000).astype(np.int32)
+    nk = np.full(20000, -1, np.int32)
+    moves, counts = _legal_batch(L, boards, player, nk, nk)
+    for i in range(20000):
+        assert (cmap[moves[i, :counts[i]].astype(np.int64)] >= 0).all(), i
