@@ -141,8 +141,13 @@ def lib():
     global _lib
     if _lib is None:
         if not os.path.exists(LIB_PATH):
-            raise XqError("libxq_hip.so is not built (%s): run `python -c 'import __graft_entry__ as g; g.build()'`; "
-                          "the HIP path has no CPU fallback" % LIB_PATH)
+            # a fresh checkout: compile in-tree if the toolchain is here (seconds); never fall back to CPU
+            try:
+                build()
+            except Exception as ex:
+                raise XqError("libxq_hip.so is not built (%s) and could not be compiled (%s): run "
+                              "`python -c 'import __graft_entry__ as g; g.build()'`; the HIP path has no CPU fallback"
+                              % (LIB_PATH, ex))
         _preload_torch_hip_runtime()
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in _SIGNATURES.items():

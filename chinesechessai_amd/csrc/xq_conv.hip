@@ -40,6 +40,18 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float a, float b)
     return *reinterpret_cast<uint32_t *>(&v);
 }
 
+// ReLU on two packed bf16: a negative bf16 has its sign bit set, i.e. is a negative int16, so
+// max(int16, 0) per half zeroes exactly the negative values (-0.0 becomes +0.0, NaN payloads with
+// the sign bit set become 0 — the fp32 path would keep them; activations are finite here).
+__device__ __forceinline__ uint32_t relu_bf16x2(uint32_t w)
+{
+    typedef __attribute__((ext_vector_type(2))) short s16x2;
+    s16x2 v = *reinterpret_cast<s16x2 *>(&w);
+    s16x2 z = { 0, 0 };
+    v = __builtin_elementwise_max(v, z);
+    return *reinterpret_cast<uint32_t *>(&v);
+}
+
 __device__ __forceinline__ float bf16_lo(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf16_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
 
@@ -263,6 +275,14 @@ __global__ __launch_bounds__(NB * 128, 2) void k_conv3x3_b(const uint16_t *__res
     // ---- epilogue: +bias -> bf16 -> the board's region [pixel][128 cout] (both channel halves) ----
     const bool early_relu = relu && !res;       // without a residual the ReLU is applied here and
                                                 // the way out is a plain copy
+    // staging address of pixel p, channel chunk c: row base | ((c ^ (p & 15)) << 4) | 8h, i.e.
+    // sbase ^ (c_const << 4) with the per-lane part folded into sbase
+    int sbase[3];
+#pragma unroll
+    for (int nt = 0; nt < 3; nt++) {
+        const int p = opix[nt] < PIX ? opix[nt] : 0;
+        sbase[nt] = (act_off + p * 256 + 8 * h + ((p & 15) << 4)) ^ (hc << 7);
+    }
 #pragma unroll
     for (int mt = 0; mt < 2; mt++) {
 #pragma unroll
@@ -271,17 +291,12 @@ __global__ __launch_bounds__(NB * 128, 2) void k_conv3x3_b(const uint16_t *__res
             const f32x4 b4 = *reinterpret_cast<const f32x4 *>(lbias + c0);
 #pragma unroll
             for (int nt = 0; nt < 3; nt++) {
-                const int p = opix[nt];
-                if (p < PIX) {
-                    float v0 = acc[mt][nt][4 * q + 0] + b4[0], v1 = acc[mt][nt][4 * q + 1] + b4[1];
-                    float v2 = acc[mt][nt][4 * q + 2] + b4[2], v3 = acc[mt][nt][4 * q + 3] + b4[3];
-                    if (early_relu) {
-                        v0 = v0 > 0.f ? v0 : 0.f; v1 = v1 > 0.f ? v1 : 0.f;
-                        v2 = v2 > 0.f ? v2 : 0.f; v3 = v3 > 0.f ? v3 : 0.f;
-                    }
-                    uint2 pk = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
-                    const int chunk = (c0 * 2) / 16, inner = (c0 * 2) % 16;
-                    *reinterpret_cast<uint2 *>(my_act + p * 256 + ((chunk ^ (p & 15)) * 16) + inner) = pk;
+                if (nt < 2 || opix[nt] < PIX) {                 // tiles 0 and 1 are always real pixels
+                    const float v0 = acc[mt][nt][4 * q + 0] + b4[0], v1 = acc[mt][nt][4 * q + 1] + b4[1];
+                    const float v2 = acc[mt][nt][4 * q + 2] + b4[2], v3 = acc[mt][nt][4 * q + 3] + b4[3];
+                    uint32_t w0 = pack_bf16x2(v0, v1), w1 = pack_bf16x2(v2, v3);
+                    if (early_relu) { w0 = relu_bf16x2(w0); w1 = relu_bf16x2(w1); }
+                    *reinterpret_cast<uint2 *>(lds + (sbase[nt] ^ ((mt * 4 + q) << 4))) = make_uint2(w0, w1);
                 }
             }
         }
@@ -304,9 +319,9 @@ __global__ __launch_bounds__(NB * 128, 2) void k_conv3x3_b(const uint16_t *__res
                 if (rsrc) {
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
-                        float lo = bf16_lo(wv[k]) + bf16_lo(rv[k]), hi = bf16_hi(wv[k]) + bf16_hi(rv[k]);
-                        if (relu) { lo = lo > 0.f ? lo : 0.f; hi = hi > 0.f ? hi : 0.f; }
+                        const float lo = bf16_lo(wv[k]) + bf16_lo(rv[k]), hi = bf16_hi(wv[k]) + bf16_hi(rv[k]);
                         wv[k] = pack_bf16x2(lo, hi);
+                        if (relu) wv[k] = relu_bf16x2(wv[k]);
                     }
                 }
                 dst[i] = make_uint4(wv[0], wv[1], wv[2], wv[3]);
