@@ -341,22 +341,23 @@ __global__ __launch_bounds__(NB * 128, 2) void k_conv3x3_b(const uint16_t *__res
 //   3 pixel tiles x 2 channel tiles x 8 k-steps of v_mfma_f32_32x32x16_bf16 (D = W . X^T);
 //   weights [64 rows (40 used)][128] are staged once per workgroup.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 1) void k_heads(const uint16_t *__restrict__ x, const uint16_t *__restrict__ w,
+template <int HNB>   // boards (= waves) per workgroup
+__global__ __launch_bounds__(HNB * 64, 2) void k_heads(const uint16_t *__restrict__ x, const uint16_t *__restrict__ w,
                                                   const float *__restrict__ bias, uint16_t *__restrict__ P,
                                                   uint16_t *__restrict__ V, int G)
 {
     constexpr int ACT_BYTES = PIX * 256;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    uint8_t *wl = lds + 4 * ACT_BYTES;                                    // [64][256 B], swizzled
+    uint8_t *wl = lds + HNB * ACT_BYTES;                                  // [64][256 B], swizzled
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int board = blockIdx.x * 4 + wave;
+    const int board = blockIdx.x * HNB + wave;
     const bool board_ok = board < G;
     uint8_t *my_act = lds + wave * ACT_BYTES;
-    {   // weights: 64 rows x 16 chunks = 1024 chunks = 4 DMA pieces per wave
+    {   // weights: 64 rows x 16 chunks = 1024 chunks = 16 DMA pieces per workgroup
         const uint8_t *src = reinterpret_cast<const uint8_t *>(w);
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int q0 = (wave * 4 + j) * 64, q = q0 + lane, row = q >> 4, cp = q & 15;
+        for (int j = 0; j < 16 / HNB; j++) {
+            const int q0 = (wave * (16 / HNB) + j) * 64, q = q0 + lane, row = q >> 4, cp = q & 15;
             dma16(src + row * 256 + ((cp ^ (row & 15)) * 16), wl + q0 * 16);
         }
     }
@@ -487,15 +488,16 @@ extern "C" int xq_heads_nhwc_bf16(void *stream, const void *x, const void *w, co
                                   void *value_out, int n_boards)
 {
     if (!x || !w || !bias || !policy_out || !value_out || n_boards <= 0) return XQ_E_INVALID;
-    constexpr int LDS = 4 * PIX * 256 + 64 * 256;
+    constexpr int HNB = 2;                                   // 62 KB LDS -> 2 workgroups per CU
+    constexpr int LDS = HNB * PIX * 256 + 64 * 256;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_heads), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) !=
-            hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_heads<HNB>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                LDS) != hipSuccess)
             return XQ_E_HIP;
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_heads, dim3((n_boards + 3) / 4), dim3(256), LDS, reinterpret_cast<hipStream_t>(stream),
+    hipLaunchKernelGGL(k_heads<HNB>, dim3((n_boards + HNB - 1) / HNB), dim3(HNB * 64), LDS, reinterpret_cast<hipStream_t>(stream),
                        (const uint16_t *)x, (const uint16_t *)w, (const float *)bias, (uint16_t *)policy_out,
                        (uint16_t *)value_out, n_boards);
     return hipGetLastError() == hipSuccess ? 0 : XQ_E_HIP;
