@@ -143,6 +143,7 @@ def main():
     ap.add_argument("--policy-columns", default="all", choices=["all", "reachable"],
                     help="'reachable' (opt-in): policy FC restricted to the 2.6k of 8,100 columns that can ever be a legal "
                          "move (result-identical; the default keeps the reference's full head)")
+    ap.add_argument("--fused-tower", type=int, default=1, help="1 = whole trunk in one launch (k_tower), 0 = one launch per convolution")
     ap.add_argument("--conv-variant", type=int, default=0, help="diagnostic: 1 = 2 boards/WG, 2 = 4 boards/WG (0 = library default)")
     args = ap.parse_args()
 
@@ -175,7 +176,8 @@ def main():
     torch.manual_seed(0)                                   # same random-init weights on every rank
     net = ChessNet(num_blocks=args.blocks).eval().cuda()
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-    ev = TorchNetEvaluator(net, dtype=dtype, chunk=args.net_chunk or None, policy_columns=args.policy_columns)
+    ev = TorchNetEvaluator(net, dtype=dtype, chunk=args.net_chunk or None, policy_columns=args.policy_columns,
+                           fused_tower=bool(args.fused_tower))
     stream = torch.cuda.current_stream().cuda_stream
     records = torch.zeros(G * _lib.MAX_PLIES * xd.RECORD_BYTES, dtype=torch.uint8, device="cuda")
 
@@ -253,9 +255,16 @@ def main():
         bpd = tree_bytes_per_descent()
         tree_gbs = (bpd * G * prof["search_launches"]) / (prof["search_ms"] * 1e-3) / 1e9 if prof["search_ms"] > 0 else 0.0
         # dominant kernel: the hand-written fused conv (2 per residual block, 128 -> 128 channels)
-        n_conv = 2 * args.blocks * len(tower_events)
+        fused = bool(args.fused_tower) and ev.inet.use_hip_conv
         conv_ms = sum(a.elapsed_time(b) for a, b in tower_events)
-        conv_fl = 2.0 * G * 90 * 128 * 9 * 128
+        if fused:       # k_tower: conv1 + 2*blocks convs + both heads per launch
+            n_conv = len(tower_events)
+            conv_fl = 2.0 * G * 90 * (16 * 9 * 128 + 2 * args.blocks * 128 * 9 * 128 + 128 * 40)
+            kname, kdesc = "k_tower", "hand-written single-launch trunk: conv3x3(16->128) + %d fused residual convs + 1x1 heads, activations resident in LDS" % (2 * args.blocks)
+        else:
+            n_conv = 2 * args.blocks * len(tower_events)
+            conv_fl = 2.0 * G * 90 * 128 * 9 * 128
+            kname, kdesc = "k_conv3x3_b<128>", "hand-written fused conv3x3+bias+residual+ReLU"
         conv_tflops = conv_fl * n_conv / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
         out = {
             "metric": "self-play games/sec @ 50 MCTS sims" if S == 50 else "self-play games/sec @ %d MCTS sims" % S,
@@ -275,10 +284,9 @@ def main():
                        "parallelism": "games sharded x%d, all-gather of samples at step end" % world},
             "roofline": {"bound": "mfma", "achieved": conv_tflops, "peak": MFMA_PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": conv_tflops / MFMA_PEAK_BF16_TFLOPS,
-                         "traffic": pmc_traffic("k_conv3x3_b<128>", G, S, args.blocks, fetch_factor=2.0),
-                         "kernel": "k_conv3x3_b<128> (hand-written fused conv3x3+bias+residual+ReLU; %d launches of %d "
-                                   "boards, %.4f ms avg; %.0f%% of the step)" % (
-                                       n_conv, G, conv_ms / max(n_conv, 1), 100.0 * conv_ms / (dt * 1e3)),
+                         "traffic": pmc_traffic(kname, G, S, args.blocks, fetch_factor=2.0),
+                         "kernel": "%s (%s; %d launches of %d boards, %.4f ms avg; %.0f%% of the step)" % (
+                             kname, kdesc, n_conv, G, conv_ms / max(n_conv, 1), 100.0 * conv_ms / (dt * 1e3)),
                          "flops_per_launch": conv_fl},
             "roofline_net": {"bound": "mfma", "achieved": net_tflops, "peak": MFMA_PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                              "frac": net_tflops / MFMA_PEAK_BF16_TFLOPS, "traffic": None,

@@ -10,7 +10,8 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libxq_hip.so")
-SOURCES = [os.path.join(CSRC, "xq_engine.hip"), os.path.join(CSRC, "xq_conv.hip"), os.path.join(CSRC, "xq_replay.hip")]
+SOURCES = [os.path.join(CSRC, "xq_engine.hip"), os.path.join(CSRC, "xq_conv.hip"), os.path.join(CSRC, "xq_replay.hip"),
+           os.path.join(CSRC, "xq_tower.hip")]
 HEADERS = [os.path.join(CSRC, "xq_device.hpp"), os.path.join(_HERE, "..", "include", "xq_selfplay.h")]
 
 MAX_MOVES = 128
@@ -122,6 +123,7 @@ _SIGNATURES = {
     "xq_conv3x3_nhwc_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_int, C.c_int, C.c_int]),
     "xq_heads_nhwc_bf16": (C.c_int, [C.c_void_p] * 6 + [C.c_int]),
+    "xq_tower_nhwc_bf16": (C.c_int, [C.c_void_p] * 9 + [C.c_int, C.c_int]),
     "xq_replay_last_error": (C.c_char_p, []),
     "xq_replay_create": (C.c_int, [C.c_int, C.c_int64, C.POINTER(C.c_void_p)]),
     "xq_replay_destroy": (None, [C.c_void_p]),

@@ -169,9 +169,10 @@ class InferenceNet(nn.Module):
     Output: (logits [G, 8100], values [G]) in `dtype`.
     """
 
-    def __init__(self, net, dtype=torch.bfloat16, c_in=16, device="cuda", policy_columns="all"):
+    def __init__(self, net, dtype=torch.bfloat16, c_in=16, device="cuda", policy_columns="all", fused_tower=True):
         super().__init__()
         self.dtype = dtype
+        self.fused_tower = fused_tower                 # one launch for the whole trunk (csrc/xq_tower.hip)
         self.c_in = c_in
         self.policy_columns = policy_columns           # "all" (reference layout) | "reachable" (opt-in)
         convs = []
@@ -198,6 +199,10 @@ class InferenceNet(nn.Module):
             self.hip_w = [w.permute(2, 3, 0, 1).reshape(9, w.shape[0], w.shape[1]).to(device=device, dtype=dtype).contiguous()
                           for w, _ in convs]
             self.hip_b = [b.to(device=device, dtype=torch.float32).contiguous() for _, b in convs]
+            # the same tensors as one weight stream / one bias table for the single-launch trunk
+            self.hip_wt = (torch.stack(self.hip_w[1:]).contiguous() if self.n_blocks else
+                           torch.zeros((0, 9, 128, 128), dtype=dtype, device=device))
+            self.hip_bt = torch.stack(self.hip_b).contiguous()
         # heads: the two 1x1 convolutions share one GEMM (32 + 8 output channels)
         pw, pb = _fold_bn(net.policy_conv, net.policy_bn)
         vw, vb = _fold_bn(net.value_conv, net.value_bn)
@@ -263,8 +268,38 @@ class InferenceNet(nn.Module):
             self.tower_events.append(ev)
         return cur.permute(0, 3, 1, 2)                    # logical NCHW, channels-last strides
 
+    def _head_buffers(self, g, device):
+        if self._hbuf is None or self._hbuf[0].shape[0] != g:
+            self._hbuf = (torch.empty((g, 2880), dtype=torch.bfloat16, device=device),
+                          torch.empty((g, 720), dtype=torch.bfloat16, device=device))
+        return self._hbuf
+
+    def trunk_hip(self, x):
+        """planes -> (policy-head activations [G, 2880], value-head activations [G, 720]) in one
+        launch of k_tower: activations stay in LDS across all layers."""
+        from . import _lib
+        g = x.shape[0]
+        xin = x.permute(0, 2, 3, 1)
+        assert xin.is_contiguous() and xin.shape[-1] == 16
+        hp, hv = self._head_buffers(g, x.device)
+        ev = None
+        if self.tower_events is not None:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        _lib.check(_lib.lib().xq_tower_nhwc_bf16(torch.cuda.current_stream().cuda_stream, xin.data_ptr(),
+                                                 self.hip_w[0].data_ptr(), self.hip_wt.data_ptr(), self.hip_bt.data_ptr(),
+                                                 self.hip_hw.data_ptr(), self.hip_hb.data_ptr(), hp.data_ptr(),
+                                                 hv.data_ptr(), g, self.n_blocks))
+        if ev is not None:
+            ev[1].record()
+            self.tower_events.append(ev)
+        return hp, hv
+
     @torch.no_grad()
     def forward(self, x, out_logits=None, out_values=None):
+        if self.use_hip_conv and x.is_cuda and self.fused_tower:
+            hp, hv = self.trunk_hip(x)
+            return self._fc(hp, hv, x.shape[0], out_logits, out_values)
         if self.use_hip_conv and x.is_cuda:
             x = self._tower_hip(x)
         else:
@@ -277,10 +312,7 @@ class InferenceNet(nn.Module):
         if self.use_hip_conv and x.is_cuda:
             # fused heads kernel: both 1x1 convs + ReLU, outputs already in the FC input layouts
             from . import _lib
-            if self._hbuf is None or self._hbuf[0].shape[0] != g:
-                self._hbuf = (torch.empty((g, 2880), dtype=torch.bfloat16, device=x.device),
-                              torch.empty((g, 720), dtype=torch.bfloat16, device=x.device))
-            hp, hv = self._hbuf
+            hp, hv = self._head_buffers(g, x.device)
             xin = x.permute(0, 2, 3, 1)
             assert xin.is_contiguous()
             _lib.check(_lib.lib().xq_heads_nhwc_bf16(torch.cuda.current_stream().cuda_stream, xin.data_ptr(),
@@ -291,6 +323,9 @@ class InferenceNet(nn.Module):
             h = h.permute(0, 2, 3, 1)                               # [G, 10, 9, 40] view
             hp = h[..., :32].reshape(g, 2880)
             hv = h[..., 32:].reshape(g, 720)
+        return self._fc(hp, hv, g, out_logits, out_values)
+
+    def _fc(self, hp, hv, g, out_logits, out_values):
         if out_logits is not None:
             policy = torch.addmm(self.pfb, hp, self.pfw.t(), out=out_logits)   # no extra 265 MB copy
         else:

@@ -237,6 +237,17 @@ int  xq_conv3x3_nhwc_bf16(void *hip_stream, const void *x_dev, const void *w_dev
 int  xq_heads_nhwc_bf16(void *hip_stream, const void *x_dev, const void *w_dev, const void *bias_dev,
                         void *policy_out_dev, void *value_out_dev, int n_boards);
 
+/* The whole convolutional trunk in one launch (neural_network.py:54-66,181-187, BN folded):
+ * conv3x3(16->128)+ReLU, n_blocks residual blocks, both 1x1 heads + ReLU; activations never leave
+ * LDS between layers.  planes [n][10][9][16] bf16, w1 [9][128][16] bf16, wt [2*n_blocks][9][128][128]
+ * bf16, bias float32 [1 + 2*n_blocks][128] (conv1 first), wh / bh as in xq_heads_nhwc_bf16;
+ * outputs as xq_heads_nhwc_bf16.  Same arithmetic as the per-layer calls (bf16 storage between
+ * layers, fp32 accumulation in the same order), except that the skip connection is added in fp32
+ * before the single bf16 rounding of a block's output (one rounding fewer per block). */
+int  xq_tower_nhwc_bf16(void *hip_stream, const void *planes_dev, const void *w1_dev, const void *wt_dev,
+                        const void *bias_dev, const void *wh_dev, const void *bh_dev, void *policy_out_dev,
+                        void *value_out_dev, int n_boards, int n_blocks);
+
 /* ------------------------------------------------------------------------------------------
  * Replay buffer: device-resident mirror of trainer.py's ReplayBuffer
  * (trainer.py:22-44: deque(maxlen) of samples, push appends a game's samples in order) and of the

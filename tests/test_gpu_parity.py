@@ -522,6 +522,72 @@ def test_fused_heads_kernel_vs_torch(L):
         assert (P[G] == 9.0).all() and (V[G] == 9.0).all()
 
 
+def test_single_launch_trunk_equals_per_layer_kernels(L):
+    """csrc/xq_tower.hip (whole trunk in one launch, activations resident in LDS) against (1) the
+    per-layer kernels (k_conv3x3_b + k_heads), which the tests above pin to fp32 torch, and (2) an
+    fp32 torch evaluation of the same folded bf16 weights with activations rounded to bf16 between
+    layers.  Same bf16 storage between layers and the same fp32 accumulation order as the
+    per-layer path, except that the skip connection is added in fp32 BEFORE the single bf16
+    rounding (the per-layer kernel rounds conv+bias first): bit-identical without residual blocks,
+    within a few bf16 ulps (2^-8 relative each) with them.  0, 1, 2 and 6 blocks, odd board counts
+    (tail workgroup), and nothing may be written past the last board."""
+    import torch
+    from chinesechessai_amd.neural_network import ChessNet, InferenceNet
+    from chinesechessai_amd import _lib
+    st = torch.cuda.current_stream().cuda_stream
+    for blocks, G in ((6, 37), (1, 2), (2, 129), (0, 5), (6, 1)):
+        torch.manual_seed(10 + blocks)
+        net = ChessNet(num_blocks=blocks).eval()
+        for m in net.modules():                                  # non-trivial running statistics
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.normal_(0, 0.1)
+                m.running_var.uniform_(0.5, 1.5)
+        inet = InferenceNet(net.cuda(), fused_tower=False)
+        planes = torch.zeros(G, 10, 9, 16, device="cuda", dtype=torch.bfloat16)
+        planes[..., :15] = (torch.rand(G, 10, 9, 15, device="cuda") < 0.15).to(torch.bfloat16)
+        x = planes.permute(0, 3, 1, 2)
+        cur = inet._tower_hip(x).permute(0, 2, 3, 1)
+        P0 = torch.empty(G, 2880, device="cuda", dtype=torch.bfloat16)
+        V0 = torch.empty(G, 720, device="cuda", dtype=torch.bfloat16)
+        _lib.check(L.xq_heads_nhwc_bf16(st, cur.data_ptr(), inet.hip_hw.data_ptr(), inet.hip_hb.data_ptr(),
+                                        P0.data_ptr(), V0.data_ptr(), G))
+        P1 = torch.full((G + 1, 2880), 9.0, device="cuda", dtype=torch.bfloat16)
+        V1 = torch.full((G + 1, 720), 9.0, device="cuda", dtype=torch.bfloat16)
+        _lib.check(L.xq_tower_nhwc_bf16(st, planes.data_ptr(), inet.hip_w[0].data_ptr(), inet.hip_wt.data_ptr(),
+                                        inet.hip_bt.data_ptr(), inet.hip_hw.data_ptr(), inet.hip_hb.data_ptr(),
+                                        P1.data_ptr(), V1.data_ptr(), G, blocks))
+        torch.cuda.synchronize()
+        assert P0.abs().max().item() > 0
+        assert (P1[G] == 9.0).all() and (V1[G] == 9.0).all()
+        if blocks == 0:
+            assert torch.equal(P1[:G].view(torch.int16), P0.view(torch.int16)), (blocks, G)
+            assert torch.equal(V1[:G].view(torch.int16), V0.view(torch.int16)), (blocks, G)
+        # fp32 torch chain on the same bf16 weights, bf16 rounding between layers
+        import torch.nn.functional as F
+        def cw(i):
+            w = inet.hip_w[i].float()                              # [9][128][cin]
+            return w.reshape(3, 3, 128, -1).permute(2, 3, 0, 1)
+        a = torch.relu(F.conv2d(x.float(), cw(0), inet.hip_b[0], padding=1)).bfloat16().float()
+        for i in range(blocks):
+            y = torch.relu(F.conv2d(a, cw(1 + 2 * i), inet.hip_b[1 + 2 * i], padding=1)).bfloat16().float()
+            a = torch.relu(F.conv2d(y, cw(2 + 2 * i), inet.hip_b[2 + 2 * i], padding=1) + a).bfloat16().float()
+        hd = torch.relu(a.permute(0, 2, 3, 1).reshape(G, 90, 128) @ inet.hip_hw.float().t() + inet.hip_hb)
+        scale = max(1.0, hd.abs().max().item())
+        tol = 2 ** -8 * scale * (2 + blocks)                       # one ulp per rounding point on the path
+        for got, name in ((P1[:G], "tower"), (P0, "per-layer")):
+            assert (got.float().reshape(G, 90, 32) - hd[..., :32]).abs().max().item() <= tol, (name, blocks, G)
+        for got, name in ((V1[:G], "tower"), (V0, "per-layer")):
+            assert (got.float().reshape(G, 90, 8) - hd[..., 32:40]).abs().max().item() <= tol, (name, blocks, G)
+        assert (P1[:G].float() - P0.float()).abs().max().item() <= tol
+        # and through the module: both modes give the same logits / values within the same bound
+        inet_f = InferenceNet(net, fused_tower=True)
+        la, va = inet(x)
+        lb, vb = inet_f(x)
+        assert (la.float() - lb.float()).abs().max().item() <= 0.05 * max(1.0, la.float().abs().max().item())
+        assert (va.float() - vb.float()).abs().max().item() <= 0.05
+    assert L.xq_tower_nhwc_bf16(st, None, None, None, None, None, None, None, None, 4, 6) == -1
+
+
 def test_real_network_game_runs_and_invariants(L):
     """Statistical parity with the real net is bounded by H2: here the invariants
     every reference game satisfies — visit totals S-8 per ply (A10), pi sums to 1, z from the
