@@ -17,6 +17,7 @@
 #include "../../include/xq_selfplay.h"
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -30,11 +31,11 @@ constexpr int ACT_BYTES = PIX * 256;          // one board, 128 channels bf16
 constexpr int WBUF_BYTES = COUT * 128;        // one weight stage: [128 cout][64 cin] bf16
 constexpr int LDS_BYTES = 2 * ACT_BYTES + 2 * WBUF_BYTES + 256 + 2 * 512;
 
-__device__ __forceinline__ uint32_t pack_bf16x2(float a, float b)
+__device__ __forceinline__ uint32_t pack_bf16x2(float a, float b)     // RNE, a in the low half
 {
-    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
-    bf16x2 v = { (__bf16)a, (__bf16)b };
-    return *reinterpret_cast<uint32_t *>(&v);
+    uint32_t r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
 }
 __device__ __forceinline__ uint32_t relu_bf16x2(uint32_t w)      // max(int16, 0) per half
 {
@@ -72,21 +73,35 @@ struct TowerArgs {
     uint16_t *P;               // [G][90][32]
     uint16_t *V;               // [G][90][8]
     int G, nblocks;
+    unsigned long long *stamps;   // diagnostic builds only: 64 u64 per workgroup
 };
 
+template <bool STAMP>
 __global__ __launch_bounds__(256, 2) void k_tower(TowerArgs A)
 {
+    // LDS: [weight stages 2 x 16 KB][activations 2 boards x 23,040 B][zero row 256 B][bias 2 x 512 B]
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    uint8_t *wbuf = lds + 2 * ACT_BYTES;
-    uint8_t *zrow = wbuf + 2 * WBUF_BYTES;
-    float *lbias = reinterpret_cast<float *>(zrow + 256);            // [2][128]
+    constexpr int ACT0 = 2 * WBUF_BYTES, ZROW = ACT0 + 2 * ACT_BYTES, BIAS = ZROW + 256;
+    uint8_t *wbuf = lds;
+    float *lbias = reinterpret_cast<float *>(lds + BIAS);            // [2][128]
 
+    auto stamp = [&](int slot) {
+        if constexpr (STAMP) {
+            const unsigned long long t = __builtin_amdgcn_s_memtime();
+            if (threadIdx.x == 0) A.stamps[(size_t)blockIdx.x * 64 + slot] = t;
+            if (slot == 0 || slot == 61) {
+                const unsigned long long rt = __builtin_amdgcn_s_memrealtime();
+                if (threadIdx.x == 0) A.stamps[(size_t)blockIdx.x * 64 + (slot == 0 ? 62 : 63)] = rt;
+            }
+        }
+    };
+    stamp(0);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wb_ = wave >> 1, hc = wave & 1;                         // board in workgroup, channel half
     const int board = blockIdx.x * 2 + wb_;
     const bool board_ok = board < A.G;
-    const int act_off = wb_ * ACT_BYTES, wbuf_off = 2 * ACT_BYTES, zrow_off = wbuf_off + 2 * WBUF_BYTES;
+    const int act_off = ACT0 + wb_ * ACT_BYTES;
     const int r32 = lane & 31, h = lane >> 5;
 
     int opix[3];
@@ -116,11 +131,26 @@ __global__ __launch_bounds__(256, 2) void k_tower(TowerArgs A)
 
     f32x16 acc[2][3];
     uint2 xres[2][4][3];                  // block input (residual), packed bf16 in accumulator layout
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+            for (int nt = 0; nt < 3; nt++)
+#pragma unroll
+                for (int i = 0; i < 16; i++) acc[mt][nt][i] = 0.f;
+    };
+    auto mfma6 = [&](const bf16x8 (&af)[2], const bf16x8 (&bf)[3]) {
+#pragma unroll
+        for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+            for (int nt = 0; nt < 3; nt++)
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mt], bf[nt], acc[mt][nt], 0, 0, 0);
+    };
 
     // ---------------------------------------------------------------- input conv (16 -> 128)
     // planes rows are 32 B (2 chunks); swizzle (row / 8) & 1; conv1 tap slices [128][16] = 4 KB
-    if (tid < 16) reinterpret_cast<uint4 *>(zrow)[tid] = make_uint4(0, 0, 0, 0);
-    if (tid >= 64 && tid < 96) reinterpret_cast<f32x4 *>(lbias)[tid - 64] = reinterpret_cast<const f32x4 *>(A.bias)[tid - 64];
+    if (tid < 16) reinterpret_cast<uint4 *>(lds + ZROW)[tid] = make_uint4(0, 0, 0, 0);
+    if (wave == 1 && lane < 32) dma16(A.bias + lane * 4, lbias);
     auto stage_w1 = [&](int tap, int buf) {           // 256 chunks: one piece per wave
         const int q0 = wave * 64, q = q0 + lane, row = q >> 1, cp = q & 1;
         dma16(reinterpret_cast<const uint8_t *>(A.w1) + (size_t)tap * COUT * 32 + row * 32 + ((cp ^ ((row >> 3) & 1)) * 16),
@@ -135,12 +165,7 @@ __global__ __launch_bounds__(256, 2) void k_tower(TowerArgs A)
             if (q < PIX * 2) dma16(src + p * 32 + ((cp ^ ((p >> 3) & 1)) * 16), lds + act_off + q0 * 16);
         }
     }
-#pragma unroll
-    for (int mt = 0; mt < 2; mt++)
-#pragma unroll
-        for (int nt = 0; nt < 3; nt++)
-#pragma unroll
-            for (int i = 0; i < 16; i++) acc[mt][nt][i] = 0.f;
+    zero_acc();
     __syncthreads();
     for (int tap = 0; tap < 9; tap++) {
         const int buf = tap & 1;
@@ -151,7 +176,7 @@ __global__ __launch_bounds__(256, 2) void k_tower(TowerArgs A)
         for (int nt = 0; nt < 3; nt++) {
             const bool ok = (vmask[nt] >> tap) & 1u;
             const int sp = opix[nt] + off;
-            const int a = ok ? act_off + sp * 32 + ((((sp >> 3) & 1) ^ h) << 4) : zrow_off + (h << 4);
+            const int a = ok ? act_off + sp * 32 + ((((sp >> 3) & 1) ^ h) << 4) : ZROW + (h << 4);
             bf[nt] = *reinterpret_cast<const bf16x8 *>(lds + a);
         }
 #pragma unroll
@@ -159,16 +184,15 @@ __global__ __launch_bounds__(256, 2) void k_tower(TowerArgs A)
             const int row = hc * 64 + mt * 32 + r32;
             af[mt] = *reinterpret_cast<const bf16x8 *>(wbuf + buf * 4096 + row * 32 + ((h ^ ((row >> 3) & 1)) * 16));
         }
-#pragma unroll
-        for (int mt = 0; mt < 2; mt++)
-#pragma unroll
-            for (int nt = 0; nt < 3; nt++)
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mt], bf[nt], acc[mt][nt], 0, 0, 0);
+        mfma6(af, bf);
         __syncthreads();
     }
+    stamp(1);
 
-    // weight stream of the 128-channel layers: stage = [128 cout][64 cin], 16 pieces per stage
-    const int nlayers = 2 * A.nblocks;
+    // weight stream of the 128-channel layers, one global sequence of stages across all layers:
+    // stage g = (layer, tap, K-slice) = [128 cout][64 cin] = 16 pieces of 1 KB, 4 per wave, into
+    // buffer g & 1 (18 stages per layer: the parity is the K-slice)
+    const int nlayers = 2 * A.nblocks, nstages = nlayers * 18;
     const rsrc_t wrsrc = make_rsrc(A.wt, nlayers * 9 * COUT * COUT * 2);
     int wsrc[4];
 #pragma unroll
@@ -176,22 +200,43 @@ __global__ __launch_bounds__(256, 2) void k_tower(TowerArgs A)
         const int q = (wave * 4 + j) * 64 + lane, row = q >> 3, cp = q & 7;
         wsrc[j] = row * 256 + ((cp ^ ((row >> 1) & 7)) * 16);
     }
-    auto stage_weights = [&](int layer, int st, int buf) {
-        const int soff = ((layer * 9 + (st >> 1)) * COUT * COUT + (st & 1) * 64) * 2;
+    auto stage_weights = [&](int g, int buf) {
+        const int soff = (g >> 1) * (COUT * COUT * 2) + (g & 1) * 128;
 #pragma unroll
         for (int j = 0; j < 4; j++) dma16_buf(wrsrc, wsrc[j], soff, wbuf + buf * WBUF_BYTES + (wave * 4 + j) * 1024);
     };
-    int aoff[2][4];                               // weight fragment offsets inside a stage buffer
+    // A fragment of (mt, K-step kk) in a stage buffer: abase ^ (kk << 5), + mt * 4096
+    const int abase = (hc * 64 + r32) * 128 + ((h ^ ((r32 >> 1) & 7)) << 4);
+    auto load_a = [&](bf16x8 (&af)[2], int sl, int kk) {
+        const int a = abase ^ (kk << 5);
 #pragma unroll
-    for (int mt = 0; mt < 2; mt++)
+        for (int mt = 0; mt < 2; mt++)
+            af[mt] = *reinterpret_cast<const bf16x8 *>(lds + a + sl * WBUF_BYTES + mt * 4096);
+    };
+    auto load_b = [&](bf16x8 (&bf)[3], const int (&a0)[3], int cconst) {
 #pragma unroll
-        for (int kk = 0; kk < 4; kk++) {
-            const int row = hc * 64 + mt * 32 + r32, cw = kk * 2 + h;
-            aoff[mt][kk] = row * 128 + ((cw ^ ((row >> 1) & 7)) * 16);
+        for (int nt = 0; nt < 3; nt++) bf[nt] = *reinterpret_cast<const bf16x8 *>(lds + (a0[nt] ^ cconst));
+    };
+    auto tap_addr = [&](int (&a0)[3], int tap) {
+        const int off = (tap / 3 - 1) * 9 + (tap % 3 - 1);
+#pragma unroll
+        for (int nt = 0; nt < 3; nt++) {
+            const bool ok = (vmask[nt] >> tap) & 1u;
+            const int sp = opix[nt] + off;
+            a0[nt] = ok ? act_off + sp * 256 + (((sp & 15) ^ h) << 4) : ZROW + (h << 4);
         }
+    };
 
-    // epilogue: acc + bias [+ residual] -> ReLU -> bf16 -> LDS rows in place (+ keep as next residual)
-    auto epilogue = [&](const float *lb, bool add_res, bool keep_res) {
+    // epilogue: acc + bias [+ residual] -> ReLU -> bf16 -> LDS rows in place (+ keep as next residual).
+    // The store addresses are derived here from one base per tile (opaque to the optimiser: hoisted
+    // out of the layer loop they would occupy 24 registers the fragment double buffer needs).
+    auto epilogue = [&](const float *lb, auto add_res, auto keep_res) {
+        int sb[3];
+#pragma unroll
+        for (int nt = 0; nt < 3; nt++) {
+            sb[nt] = sbase[nt];
+            asm volatile("" : "+v"(sb[nt]));
+        }
 #pragma unroll
         for (int mt = 0; mt < 2; mt++)
 #pragma unroll
@@ -202,79 +247,95 @@ __global__ __launch_bounds__(256, 2) void k_tower(TowerArgs A)
                 for (int nt = 0; nt < 3; nt++) {
                     float v0 = acc[mt][nt][4 * q + 0] + b4[0], v1 = acc[mt][nt][4 * q + 1] + b4[1];
                     float v2 = acc[mt][nt][4 * q + 2] + b4[2], v3 = acc[mt][nt][4 * q + 3] + b4[3];
-                    if (add_res) {
+                    if constexpr (decltype(add_res)::value) {
                         const uint2 r = xres[mt][q][nt];
                         v0 += bf16_lo(r.x); v1 += bf16_hi(r.x); v2 += bf16_lo(r.y); v3 += bf16_hi(r.y);
                     }
                     const uint2 pk = make_uint2(relu_bf16x2(pack_bf16x2(v0, v1)), relu_bf16x2(pack_bf16x2(v2, v3)));
-                    if (keep_res) xres[mt][q][nt] = pk;
+                    if constexpr (decltype(keep_res)::value) xres[mt][q][nt] = pk;
                     if (nt < 2 || opix[nt] < PIX)
-                        *reinterpret_cast<uint2 *>(lds + (sbase[nt] ^ ((mt * 4 + q) << 4))) = pk;
+                        *reinterpret_cast<uint2 *>(lds + (sb[nt] ^ ((mt * 4 + q) << 4))) = pk;
                 }
             }
     };
+    using yes = std::integral_constant<bool, true>;
+    using no = std::integral_constant<bool, false>;
 
-    // conv1 epilogue (all taps were read before the last barrier: rows are rewritten in place)
-    if (nlayers > 0) stage_weights(0, 0, 0);
-    if (tid >= 64 && tid < 96 && nlayers > 0)
-        reinterpret_cast<f32x4 *>(lbias + 128)[tid - 64] = reinterpret_cast<const f32x4 *>(A.bias + 128)[tid - 64];
-    epilogue(lbias, false, true);
+    // conv1 epilogue (all taps were read before the last barrier: rows are rewritten in place);
+    // the first two weight stages and the first tower bias land behind it
+    if (nstages > 0) {
+        stage_weights(0, 0);
+        stage_weights(1, 1);
+        if (wave == 1 && lane < 32) dma16(A.bias + 128 + lane * 4, lbias + 128);
+    }
+    epilogue(lbias, no{}, yes{});
     __syncthreads();
+    stamp(2);
 
     // ---------------------------------------------------------------- residual tower
     for (int layer = 0; layer < nlayers; layer++) {
-#pragma unroll
-        for (int mt = 0; mt < 2; mt++)
-#pragma unroll
-            for (int nt = 0; nt < 3; nt++)
-#pragma unroll
-                for (int i = 0; i < 16; i++) acc[mt][nt][i] = 0.f;
+        zero_acc();
+        if (wave == 1 && lane < 32 && layer + 1 < nlayers)          // next layer's bias, slot (layer + 2) & 1
+            dma16(A.bias + (size_t)(layer + 2) * 128 + lane * 4, lbias + (layer & 1) * 128);
+        int a0[3];
+        tap_addr(a0, 0);
+        bf16x8 fa[2][2], fb[2][3];                                  // fragment double buffer (K-step parity)
+        load_a(fa[0], 0, 0);
+        load_b(fb[0], a0, 0);
         for (int tap = 0; tap < 9; tap++) {
-            const int off = (tap / 3 - 1) * 9 + (tap % 3 - 1);
-            int a0[3];
+            int a0n[3];
+            tap_addr(a0n, tap < 8 ? tap + 1 : 8);
 #pragma unroll
-            for (int nt = 0; nt < 3; nt++) {
-                const bool ok = (vmask[nt] >> tap) & 1u;
-                const int sp = opix[nt] + off;
-                a0[nt] = ok ? act_off + sp * 256 + (((sp & 15) ^ h) << 4) : zrow_off + (h << 4);
+            for (int u = 0; u < 8; u++) {                           // 2 K-slices x 4 K-steps of 16 channels
+                const int sl = u >> 2, kk = u & 3, cur = u & 1;
+                if (kk < 3) {
+                    load_a(fa[cur ^ 1], sl, kk + 1);
+                    load_b(fb[cur ^ 1], a0, (sl * 8 + (kk + 1) * 2) << 4);
+                    mfma6(fa[cur], fb[cur]);
+                    // issue order: one fragment read of the next K-step behind each MFMA of this one
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+#pragma unroll
+                    for (int j = 0; j < 5; j++) {
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    }
+                } else {
+                    // end of a stage: every wave has its last fragments of this buffer in registers,
+                    // the next stage's pieces have landed -> fetch the next stage's first fragments and
+                    // refill this buffer two stages ahead while this K-step's MFMAs run
+                    __syncthreads();
+                    const int g = layer * 18 + tap * 2 + sl;
+                    if (sl == 0) {
+                        load_a(fa[cur ^ 1], 1, 0);
+                        load_b(fb[cur ^ 1], a0, 8 << 4);
+                    } else {                                          // (tap 8: a dead prefetch of tap 8 again)
+                        load_a(fa[cur ^ 1], 0, 0);
+                        load_b(fb[cur ^ 1], a0n, 0);
+                    }
+                    // (the last two stages of the tower refetch the final stage into the dead buffer
+                    // rather than branch: a branch here would split the MFMA block)
+                    stage_weights(g + 2 < nstages ? g + 2 : nstages - 1, sl);
+                    mfma6(fa[cur], fb[cur]);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {                     // one LDS-DMA piece per MFMA gap
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    }
+                }
             }
 #pragma unroll
-            for (int sl = 0; sl < 2; sl++) {
-                const int st = tap * 2 + sl;                       // buffer parity == sl (18 stages per layer)
-                if (st + 1 < 18) stage_weights(layer, st + 1, sl ^ 1);
-                else if (layer + 1 < nlayers) {
-                    stage_weights(layer + 1, 0, 0);                // next layer's first slice + its bias
-                    if (tid >= 64 && tid < 96)
-                        reinterpret_cast<f32x4 *>(lbias + (layer & 1) * 128)[tid - 64] =
-                            reinterpret_cast<const f32x4 *>(A.bias + (size_t)(layer + 2) * 128)[tid - 64];
-                }
-                const int wb_off = wbuf_off + sl * WBUF_BYTES;
-                bf16x8 bfr[2][3], afr[2][2];
-                auto load_frags = [&](int kk, bf16x8 (&bf)[3], bf16x8 (&af)[2]) {
-                    const int cconst = (sl * 8 + kk * 2) << 4;
-#pragma unroll
-                    for (int nt = 0; nt < 3; nt++) bf[nt] = *reinterpret_cast<const bf16x8 *>(lds + (a0[nt] ^ cconst));
-#pragma unroll
-                    for (int mt = 0; mt < 2; mt++) af[mt] = *reinterpret_cast<const bf16x8 *>(lds + wb_off + aoff[mt][kk]);
-                };
-                load_frags(0, bfr[0], afr[0]);
-#pragma unroll
-                for (int kk = 0; kk < 4; kk++) {
-                    const int cur = kk & 1;
-                    if (kk + 1 < 4) load_frags(kk + 1, bfr[cur ^ 1], afr[cur ^ 1]);
-#pragma unroll
-                    for (int mt = 0; mt < 2; mt++)
-#pragma unroll
-                        for (int nt = 0; nt < 3; nt++)
-                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[cur][mt], bfr[cur][nt], acc[mt][nt], 0, 0, 0);
-                }
-                __syncthreads();
-            }
+            for (int nt = 0; nt < 3; nt++) a0[nt] = a0n[nt];
         }
-        // bias slot of tower layer L is (L + 1) & 1 (slot 0 held conv1's)
-        const bool second = layer & 1;                             // second conv of a block: + skip
-        epilogue(lbias + ((layer + 1) & 1) * 128, second, second);
+        if (layer < 28) stamp(3 + 2 * layer);
+        // bias slot of tower layer L is (L + 1) & 1 (slot 0 held conv1's); odd layers close a block
+        if (layer & 1) epilogue(lbias + ((layer + 1) & 1) * 128, yes{}, yes{});
+        else epilogue(lbias + ((layer + 1) & 1) * 128, no{}, no{});
         __syncthreads();
+        if (layer < 28) stamp(4 + 2 * layer);
     }
 
     // ---------------------------------------------------------------- heads (1x1, 128 -> 32 + 8)
@@ -304,7 +365,8 @@ __global__ __launch_bounds__(256, 2) void k_tower(TowerArgs A)
             hacc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, hacc[nt], 0, 0, 0);
         }
     }
-    if (!board_ok) return;
+    stamp(60);
+    if (!board_ok) { stamp(61); return; }
     uint8_t *Pb = reinterpret_cast<uint8_t *>(A.P) + (size_t)board * PIX * 64;
     uint8_t *Vb = reinterpret_cast<uint8_t *>(A.V) + (size_t)board * PIX * 16;
 #pragma unroll
@@ -324,26 +386,79 @@ __global__ __launch_bounds__(256, 2) void k_tower(TowerArgs A)
             }
         }
     }
+    stamp(61);
 }
 
 }  // namespace
 
-extern "C" int xq_tower_nhwc_bf16(void *stream, const void *planes, const void *w1, const void *wt, const void *bias,
-                                  const void *wh, const void *bh, void *policy_out, void *value_out, int n_boards,
-                                  int n_blocks)
+template <bool STAMP>
+static int launch_tower(void *stream, const void *planes, const void *w1, const void *wt, const void *bias, const void *wh,
+                        const void *bh, void *policy_out, void *value_out, int n_boards, int n_blocks, void *stamps)
 {
     if (!planes || !w1 || !bias || !wh || !bh || !policy_out || !value_out || n_boards <= 0 || n_blocks < 0 ||
         (n_blocks > 0 && !wt) || n_blocks > 64)
         return XQ_E_INVALID;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tower), hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tower<STAMP>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 LDS_BYTES) != hipSuccess)
             return XQ_E_HIP;
         attr_set = true;
     }
     TowerArgs a{ (const uint16_t *)planes, (const uint16_t *)w1, (const uint16_t *)wt, (const float *)bias,
-                 (const uint16_t *)wh, (const float *)bh, (uint16_t *)policy_out, (uint16_t *)value_out, n_boards, n_blocks };
-    hipLaunchKernelGGL(k_tower, dim3((n_boards + 1) / 2), dim3(256), LDS_BYTES, reinterpret_cast<hipStream_t>(stream), a);
+                 (const uint16_t *)wh, (const float *)bh, (uint16_t *)policy_out, (uint16_t *)value_out, n_boards, n_blocks,
+                 (unsigned long long *)stamps };
+    hipLaunchKernelGGL(k_tower<STAMP>, dim3((n_boards + 1) / 2), dim3(256), LDS_BYTES, reinterpret_cast<hipStream_t>(stream), a);
+    return hipGetLastError() == hipSuccess ? 0 : XQ_E_HIP;
+}
+
+extern "C" int xq_tower_nhwc_bf16(void *stream, const void *planes, const void *w1, const void *wt, const void *bias,
+                                  const void *wh, const void *bh, void *policy_out, void *value_out, int n_boards,
+                                  int n_blocks)
+{
+    return launch_tower<false>(stream, planes, w1, wt, bias, wh, bh, policy_out, value_out, n_boards, n_blocks, nullptr);
+}
+
+// diagnostic only (not part of the public ABI): s_memtime phase stamps, 64 u64 per workgroup
+// (0 start, 1 input conv done, 2 its epilogue, 3+2L / 4+2L main loop / epilogue of layer L, 60 heads
+// MFMAs done, 61 end, 62/63 s_memrealtime at start / end)
+extern "C" int xq_tower_debug_stamps(void *stream, const void *planes, const void *w1, const void *wt, const void *bias,
+                                     const void *wh, const void *bh, void *policy_out, void *value_out, int n_boards,
+                                     int n_blocks, void *stamps)
+{
+    if (!stamps) return XQ_E_INVALID;
+    return launch_tower<true>(stream, planes, w1, wt, bias, wh, bh, policy_out, value_out, n_boards, n_blocks, stamps);
+}
+
+// diagnostic only: what the matrix pipes sustain under this board's power cap — 2 waves per SIMD
+// issuing dependent-free v_mfma_f32_32x32x16_bf16 back to back on register operands (6 accumulators
+// per wave like the conv tile), nothing else.  tools/bench_tower.py prints it beside the kernel.
+namespace {
+__global__ __launch_bounds__(256, 2) void k_mfma_probe(const uint32_t *seed, float *out, int iters)
+{
+    bf16x8 a[2], b[3];
+    uint32_t s = seed[threadIdx.x & 63] + blockIdx.x * 2654435761u;
+    auto rnd = [&]() { s = s * 1664525u + 1013904223u; return (__bf16)(((int)(s >> 9) % 2048 - 1024) * (1.0f / 1024.0f)); };
+    for (int i = 0; i < 8; i++) { a[0][i] = rnd(); a[1][i] = rnd(); b[0][i] = rnd() > (__bf16)0.f ? rnd() : (__bf16)0.f; b[1][i] = rnd(); b[2][i] = rnd(); }
+    f32x16 acc[2][3];
+    for (int m = 0; m < 2; m++) for (int n = 0; n < 3; n++) for (int i = 0; i < 16; i++) acc[m][n][i] = 0.f;
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+#pragma unroll
+            for (int m = 0; m < 2; m++)
+#pragma unroll
+                for (int n = 0; n < 3; n++) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m], b[n], acc[m][n], 0, 0, 0);
+    }
+    float t = 0.f;
+    for (int m = 0; m < 2; m++) for (int n = 0; n < 3; n++) for (int i = 0; i < 16; i++) t += acc[m][n][i];
+    if (t == 123.456f) out[0] = t;
+}
+}  // namespace
+
+extern "C" int xq_mfma_probe(void *stream, const void *seed64_dev, void *out_dev, int n_workgroups, int iters)
+{
+    hipLaunchKernelGGL(k_mfma_probe, dim3(n_workgroups), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       (const uint32_t *)seed64_dev, (float *)out_dev, iters);
     return hipGetLastError() == hipSuccess ? 0 : XQ_E_HIP;
 }

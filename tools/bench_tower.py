@@ -1,0 +1,80 @@
+"""Micro-benchmark + phase stamps of the single-launch trunk kernel (run on the GPU box)."""
+import ctypes as C
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from chinesechessai_amd import _lib
+from chinesechessai_amd.neural_network import ChessNet, InferenceNet
+
+L = _lib.lib()
+G = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
+blocks = int(sys.argv[2]) if len(sys.argv) > 2 else 6
+st = torch.cuda.current_stream().cuda_stream
+torch.manual_seed(0)
+inet = InferenceNet(ChessNet(num_blocks=blocks).eval().cuda())
+planes = torch.zeros(G, 10, 9, 16, device="cuda", dtype=torch.bfloat16)
+planes[..., :15] = (torch.rand(G, 10, 9, 15, device="cuda") < 0.15).to(torch.bfloat16)
+P = torch.empty(G, 2880, device="cuda", dtype=torch.bfloat16)
+V = torch.empty(G, 720, device="cuda", dtype=torch.bfloat16)
+args = (st, planes.data_ptr(), inet.hip_w[0].data_ptr(), inet.hip_wt.data_ptr(), inet.hip_bt.data_ptr(),
+        inet.hip_hw.data_ptr(), inet.hip_hb.data_ptr(), P.data_ptr(), V.data_ptr(), G, blocks)
+
+
+def timeit(fn, it=20):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for _ in range(3):
+        fn()
+    e0.record()
+    for _ in range(it):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / it
+
+
+fl = 2.0 * G * 90 * (16 * 9 * 128 + 2 * blocks * 128 * 9 * 128 + 128 * 40)
+ms = timeit(lambda: L.xq_tower_nhwc_bf16(*args))
+print("k_tower G=%d blocks=%d: %.3f ms  %.1f TFLOP/s" % (G, blocks, ms, fl / ms / 1e9))
+
+fn = L.xq_tower_debug_stamps
+fn.argtypes = [C.c_void_p] * 9 + [C.c_int, C.c_int, C.c_void_p]
+nwg = (G + 1) // 2
+stamps = torch.zeros(nwg * 64, dtype=torch.int64, device="cuda")
+for _ in range(2):
+    fn(*args, stamps.data_ptr())
+torch.cuda.synchronize()
+s = stamps.cpu().numpy().reshape(nwg, 64).astype(np.float64)
+nl = 2 * blocks
+tot = s[:, 61] - s[:, 0]
+rt = s[:, 63] - s[:, 62]
+main = [np.median(s[:, 3 + 2 * l] - s[:, 2 + 2 * l]) for l in range(nl)]
+epi = [np.median(s[:, 4 + 2 * l] - s[:, 3 + 2 * l]) for l in range(nl)]
+print("input conv %d + epilogue %d | main loops %s | epilogues %s | heads %d + stores %d | WG total %d cycles" % (
+    np.median(s[:, 1] - s[:, 0]), np.median(s[:, 2] - s[:, 1]), [int(v) for v in main], [int(v) for v in epi],
+    np.median(s[:, 60] - s[:, 2 + 2 * nl]), np.median(s[:, 61] - s[:, 60]), np.median(tot)))
+print("clock %.3f GHz, kernel wall %.1f us, WG wall median %.1f us; ideal MFMA cycles per WG-pair per layer: %d" % (
+    np.median(tot / rt * 0.1), (s[:, 63].max() - s[:, 62].min()) / 100.0, np.median(rt) / 100.0, 2 * 18 * 24 * 32))
+
+# per start-order group: do the early layers stay slow in later rounds? (lockstep of co-resident workgroups)
+order = np.argsort(s[:, 62])
+grp = np.array_split(order, 16)
+print("start-order group: start us | main loop L0, L2, L4, L6, L11 | WG total")
+t0 = s[:, 62].min()
+for gi, idx in enumerate(grp):
+    m = lambda l: int(np.median(s[idx, 3 + 2 * l] - s[idx, 2 + 2 * l]))
+    print("  %2d: %7.1f..%7.1f | %6d %6d %6d %6d %6d | %d" % (
+        gi, (s[idx, 62].min() - t0) / 100.0, (s[idx, 62].max() - t0) / 100.0, m(0), m(2), m(4), m(6), m(nl - 1),
+        int(np.median(tot[idx]))))
+
+# matrix-pipe ceiling under the power cap: MFMAs only, 2 waves / SIMD, same instruction and tile
+probe = L.xq_mfma_probe
+probe.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+seed = torch.randint(0, 2 ** 31 - 1, (64,), dtype=torch.int32, device="cuda")
+outp = torch.zeros(4, device="cuda")
+for nwg_p, iters in ((512, 20000), (512, 60000)):
+    ms = timeit(lambda: probe(st, seed.data_ptr(), outp.data_ptr(), nwg_p, iters), it=3)
+    fl_p = nwg_p * 4 * iters * 24 * 2.0 * 32 * 32 * 16
+    print("MFMA-only probe (%d WGs x 4 waves, %d x 24 MFMAs): %.3f ms  %.1f TFLOP/s" % (nwg_p, iters, ms, fl_p / ms / 1e9))
