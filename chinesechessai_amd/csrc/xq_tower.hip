@@ -431,34 +431,97 @@ extern "C" int xq_tower_debug_stamps(void *stream, const void *planes, const voi
 }
 
 // diagnostic only: what the matrix pipes sustain under this board's power cap — 2 waves per SIMD
-// issuing dependent-free v_mfma_f32_32x32x16_bf16 back to back on register operands (6 accumulators
-// per wave like the conv tile), nothing else.  tools/bench_tower.py prints it beside the kernel.
+// issuing v_mfma_f32_32x32x16_bf16 back to back (6 accumulators per wave like the conv tile).
+//   mode 0: operands fixed in registers (no other activity)
+//   mode 1: operands re-read from LDS for every K-step in the conv's 2 A + 3 B pattern (random bf16
+//           data, half of the B values zero like post-ReLU activations), no barriers, no DMA
+//   mode 2: mode 1 + the conv's weight stream (4 LDS-DMA pieces of 1 KB per 24 MFMAs from a 3.5 MB
+//           L2-resident buffer), still no barriers
+// tools/bench_tower.py prints these beside the kernel: the gap between them is what the data
+// movement costs in clock under the power cap.
 namespace {
-__global__ __launch_bounds__(256, 2) void k_mfma_probe(const uint32_t *seed, float *out, int iters)
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void k_mfma_probe(const uint32_t *seed, const uint8_t *wsrc, float *out, int iters)
 {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    uint32_t s = seed[lane] + blockIdx.x * 2654435761u + tid * 40503u;
+    auto rnd = [&]() { s = s * 1664525u + 1013904223u; return s; };
+    if (MODE > 0) {
+        // 32 KB "weights" (dense random) + 46 KB "activations" (half zeros), bf16 in [-1, 1)
+        for (int i = tid; i < (32768 + 46080) / 4; i += 256) {
+            const uint32_t r = rnd();
+            const float a = ((int)((r >> 8) & 2047) - 1024) * (1.0f / 1024.0f), b = ((int)((r >> 20) & 2047) - 1024) * (1.0f / 1024.0f);
+            uint32_t w = pack_bf16x2(a, b);
+            if (i >= 8192) w = relu_bf16x2(w);
+            reinterpret_cast<uint32_t *>(lds)[i] = w;
+        }
+        __syncthreads();
+    }
     bf16x8 a[2], b[3];
-    uint32_t s = seed[threadIdx.x & 63] + blockIdx.x * 2654435761u;
-    auto rnd = [&]() { s = s * 1664525u + 1013904223u; return (__bf16)(((int)(s >> 9) % 2048 - 1024) * (1.0f / 1024.0f)); };
-    for (int i = 0; i < 8; i++) { a[0][i] = rnd(); a[1][i] = rnd(); b[0][i] = rnd() > (__bf16)0.f ? rnd() : (__bf16)0.f; b[1][i] = rnd(); b[2][i] = rnd(); }
+    for (int i = 0; i < 8; i++) {
+        a[0][i] = (__bf16)(((int)(rnd() >> 9) % 2048 - 1024) * (1.0f / 1024.0f));
+        a[1][i] = (__bf16)(((int)(rnd() >> 9) % 2048 - 1024) * (1.0f / 1024.0f));
+        for (int n = 0; n < 3; n++) {
+            const float v = ((int)(rnd() >> 9) % 2048 - 1024) * (1.0f / 1024.0f);
+            b[n][i] = (__bf16)(v > 0.f ? v : 0.f);
+        }
+    }
     f32x16 acc[2][3];
     for (int m = 0; m < 2; m++) for (int n = 0; n < 3; n++) for (int i = 0; i < 16; i++) acc[m][n][i] = 0.f;
+    const int r32 = lane & 31, h = lane >> 5, hc = wave & 1, bd = wave >> 1;
+    const int abase = (hc * 64 + r32) * 128 + ((h ^ ((r32 >> 1) & 7)) << 4);
+    rsrc_t wr = make_rsrc(wsrc, 216 * 16384);
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     for (int it = 0; it < iters; it++) {
+        if (MODE == 2) {
 #pragma unroll
-        for (int u = 0; u < 4; u++)
+            for (int j = 0; j < 4; j++)
+                dma16_buf(wr, lane * 16, ((it % 216) * 16 + wave * 4 + j) * 1024, lds + 78848 + (wave * 4 + j) * 1024 * 0);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (MODE > 0) {
+                const int sl = it & 1;
+                const int px = (it * 7 + u * 3) % 58;                       // sliding pixel window like the taps
+#pragma unroll
+                for (int m = 0; m < 2; m++)
+                    a[m] = *reinterpret_cast<const bf16x8 *>(lds + (abase ^ (u << 5)) + sl * 16384 + m * 4096);
+#pragma unroll
+                for (int n = 0; n < 3; n++) {
+                    const int sp = (px + n * 32 + r32) % 90;
+                    b[n] = *reinterpret_cast<const bf16x8 *>(lds + 32768 + bd * 23040 + sp * 256 +
+                                                               ((((sp & 15) ^ h) << 4) ^ ((sl * 8 + u * 2) << 4)));
+                }
+            }
 #pragma unroll
             for (int m = 0; m < 2; m++)
 #pragma unroll
                 for (int n = 0; n < 3; n++) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m], b[n], acc[m][n], 0, 0, 0);
+        }
     }
     float t = 0.f;
     for (int m = 0; m < 2; m++) for (int n = 0; n < 3; n++) for (int i = 0; i < 16; i++) t += acc[m][n][i];
     if (t == 123.456f) out[0] = t;
+    if (blockIdx.x == 0 && tid == 0) {       // core cycles and 100 MHz ticks of the loop -> clock under load
+        out[1] = (float)(__builtin_amdgcn_s_memtime() - c0);
+        out[2] = (float)(__builtin_amdgcn_s_memrealtime() - r0);
+    }
 }
 }  // namespace
 
-extern "C" int xq_mfma_probe(void *stream, const void *seed64_dev, void *out_dev, int n_workgroups, int iters)
+extern "C" int xq_mfma_probe(void *stream, const void *seed64_dev, const void *weights_dev, void *out_dev, int n_workgroups,
+                             int iters, int mode)
 {
-    hipLaunchKernelGGL(k_mfma_probe, dim3(n_workgroups), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                       (const uint32_t *)seed64_dev, (float *)out_dev, iters);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int lds_bytes = mode ? 80128 : 0;
+    if (mode == 0) hipLaunchKernelGGL(k_mfma_probe<0>, dim3(n_workgroups), dim3(256), 0, st, (const uint32_t *)seed64_dev, (const uint8_t *)weights_dev, (float *)out_dev, iters);
+    else {
+        const void *f = mode == 1 ? reinterpret_cast<const void *>(&k_mfma_probe<1>) : reinterpret_cast<const void *>(&k_mfma_probe<2>);
+        if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess) return XQ_E_HIP;
+        if (mode == 1) hipLaunchKernelGGL(k_mfma_probe<1>, dim3(n_workgroups), dim3(256), lds_bytes, st, (const uint32_t *)seed64_dev, (const uint8_t *)weights_dev, (float *)out_dev, iters);
+        else hipLaunchKernelGGL(k_mfma_probe<2>, dim3(n_workgroups), dim3(256), lds_bytes, st, (const uint32_t *)seed64_dev, (const uint8_t *)weights_dev, (float *)out_dev, iters);
+    }
     return hipGetLastError() == hipSuccess ? 0 : XQ_E_HIP;
 }

@@ -69,12 +69,17 @@ for gi, idx in enumerate(grp):
         gi, (s[idx, 62].min() - t0) / 100.0, (s[idx, 62].max() - t0) / 100.0, m(0), m(2), m(4), m(6), m(nl - 1),
         int(np.median(tot[idx]))))
 
-# matrix-pipe ceiling under the power cap: MFMAs only, 2 waves / SIMD, same instruction and tile
+# matrix-pipe ceiling under the power cap: same instruction and tile, 2 waves / SIMD, with and without
+# the conv's LDS fragment reads and weight stream
 probe = L.xq_mfma_probe
-probe.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+probe.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
 seed = torch.randint(0, 2 ** 31 - 1, (64,), dtype=torch.int32, device="cuda")
+wts = torch.randint(-2 ** 31, 2 ** 31 - 1, (216 * 16384 // 4,), dtype=torch.int32, device="cuda")
 outp = torch.zeros(4, device="cuda")
-for nwg_p, iters in ((512, 20000), (512, 60000)):
-    ms = timeit(lambda: probe(st, seed.data_ptr(), outp.data_ptr(), nwg_p, iters), it=3)
-    fl_p = nwg_p * 4 * iters * 24 * 2.0 * 32 * 32 * 16
-    print("MFMA-only probe (%d WGs x 4 waves, %d x 24 MFMAs): %.3f ms  %.1f TFLOP/s" % (nwg_p, iters, ms, fl_p / ms / 1e9))
+for mode, name in ((0, "registers only"), (1, "+ LDS fragment reads"), (2, "+ LDS reads + LDS-DMA weight stream")):
+    iters = 20000
+    ms = timeit(lambda: probe(st, seed.data_ptr(), wts.data_ptr(), outp.data_ptr(), 512, iters, mode), it=3)
+    fl_p = 512 * 4 * iters * 24 * 2.0 * 32 * 32 * 16
+    o = outp.cpu().numpy()
+    print("MFMA probe, %s: %.3f ms  %.1f TFLOP/s, clock %.3f GHz, %.1f cycles per MFMA per SIMD" % (
+        name, ms, fl_p / ms / 1e9, o[1] / o[2] * 0.1, o[1] / (iters * 24 * 2.0)))

@@ -1,0 +1,53 @@
+"""Summarise rocprofv3 --pmc passes into profiles/<name>.json (KB per launch, per kernel).
+
+usage: python tools/pmc_summary.py OUT.json DIR_FETCH DIR_WRITE [note]
+Each DIR is the -d output of one `rocprofv3 --pmc <COUNTER> --kernel-trace --output-format csv`
+pass (separate passes, as the MI355X guide prescribes); every *counter_collection.csv below it is read.
+"""
+import csv
+import glob
+import json
+import os
+import re
+import sys
+
+SHORT = (("k_tower", "k_tower"), ("k_conv3x3_b<16", "k_conv3x3_b<16>"), ("k_conv3x3_b<128", "k_conv3x3_b<128>"),
+         ("k_heads", "k_heads"), ("k_search_round", "k_search_round"), ("k_play_move", "k_play_move"),
+         ("k_end_search", "k_end_search"), ("k_new_games", "k_new_games"), ("k_pack_samples", "k_pack_samples"),
+         ("k_finalize", "k_finalize"), ("Cijk_", "policy_fc_gemm(hipBLASLt)"))
+
+
+def short(name):
+    for key, s in SHORT:
+        if key in name:
+            return s
+    return re.sub(r"\(.*", "", name)[:60]
+
+
+def read(d):
+    acc = {}
+    for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        with open(path, newline="") as f:
+            for row in csv.DictReader(f):
+                k = (short(row["Kernel_Name"]), row["Counter_Name"])
+                a = acc.setdefault(k, [0.0, set()])
+                a[0] += float(row["Counter_Value"])
+                a[1].add(row.get("Dispatch_Id") or row.get("Correlation_Id"))
+    return acc
+
+
+def main():
+    out, dirs, note = sys.argv[1], sys.argv[2:4], (sys.argv[4] if len(sys.argv) > 4 else "")
+    kernels = {}
+    for d in dirs:
+        for (kname, counter), (total, ids) in read(d).items():
+            e = kernels.setdefault(kname, {})
+            e["%s_KB_mean_per_launch" % counter] = total / max(len(ids), 1)
+            e["launches_%s" % counter] = len(ids)
+    json.dump({"note": note, "kernels": kernels}, open(out, "w"), indent=1)
+    for k, v in sorted(kernels.items()):
+        print(k, v)
+
+
+if __name__ == "__main__":
+    main()
