@@ -149,6 +149,8 @@ def main():
     ap.add_argument("--policy-columns", default="all", choices=["all", "reachable"],
                     help="'reachable' (opt-in): policy FC restricted to the 2.6k of 8,100 columns that can ever be a legal "
                          "move (result-identical; the default keeps the reference's full head)")
+    ap.add_argument("--tree-reuse", action="store_true", help="extension: keep the played move's subtree (no reference oracle)")
+    ap.add_argument("--virtual-loss", action="store_true", help="extension: up to 8 distinct leaves per game and round (8x the network rows)")
     ap.add_argument("--fused-tower", type=int, default=1, help="1 = whole trunk in one launch (k_tower), 0 = one launch per convolution")
     ap.add_argument("--conv-variant", type=int, default=0, help="diagnostic: 1 = 2 boards/WG, 2 = 4 boards/WG (0 = library default)")
     args = ap.parse_args()
@@ -216,6 +218,10 @@ def main():
         torch.cuda.synchronize()
 
     eng = SelfPlayEngine(G, sims=S, planes_format=ev.planes_format, device=dev, stream=stream)
+    if args.tree_reuse:
+        eng.set_tree_reuse(True)
+    if args.virtual_loss:
+        eng.set_virtual_loss(True)
     # one-time initialisation that is not part of any step, so that the timed region is clean even
     # with --warmup 0: code-object load + GEMM heuristics (one forward on the full-size buffers),
     # RCCL communicator set-up (one tiny all-gather)
@@ -253,7 +259,7 @@ def main():
 
     if rank == 0:
         games = G * world * args.steps
-        rows = G                                            # network rows per forward (one per game)
+        rows = eng.n_rows                                   # network rows per forward (one per game; x8 slots with virtual loss)
         fl = net_flops_per_row(args.blocks)
         if args.policy_columns == "reachable":                 # only the computed FC rows count
             fl -= 2 * 2880 * (8100 - ev.inet.n_policy)
@@ -265,11 +271,11 @@ def main():
         conv_ms = sum(a.elapsed_time(b) for a, b in tower_events)
         if fused:       # k_tower: conv1 + 2*blocks convs + both heads per launch
             n_conv = len(tower_events)
-            conv_fl = 2.0 * G * 90 * (16 * 9 * 128 + 2 * args.blocks * 128 * 9 * 128 + 128 * 40)
+            conv_fl = 2.0 * rows * 90 * (16 * 9 * 128 + 2 * args.blocks * 128 * 9 * 128 + 128 * 40)
             kname, kdesc = "k_tower", "hand-written single-launch trunk: conv3x3(16->128) + %d fused residual convs + 1x1 heads, activations resident in LDS" % (2 * args.blocks)
         else:
             n_conv = 2 * args.blocks * len(tower_events)
-            conv_fl = 2.0 * G * 90 * 128 * 9 * 128
+            conv_fl = 2.0 * rows * 90 * 128 * 9 * 128
             kname, kdesc = "k_conv3x3_b<128>", "hand-written fused conv3x3+bias+residual+ReLU"
         conv_tflops = conv_fl * n_conv / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
         out = {
@@ -285,14 +291,16 @@ def main():
                                        (", policy FC restricted to the %d reachable-move columns" % ev.inet.n_policy
                                         if args.policy_columns == "reachable" else "") +
                                        (", Dirichlet root noise %s, temperature 1 -> 0 at ply %d (extensions, no reference oracle)"
-                                        % (args.root_noise, args.temp_cutoff)) if (args.root_noise or args.temp_cutoff) else ""),
+                                        % (args.root_noise, args.temp_cutoff)) if (args.root_noise or args.temp_cutoff) else "") +
+                                       (", tree reuse (extension)" if args.tree_reuse else "") +
+                                       (", virtual loss: %d rows per game and round (extension)" % (rows // G) if args.virtual_loss else ""),
                        "games_per_gpu": G, "sims": S, "blocks": args.blocks, "max_moves": 70,
                        "parallelism": "games sharded x%d, all-gather of samples at step end" % world},
             "roofline": {"bound": "mfma", "achieved": conv_tflops, "peak": MFMA_PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": conv_tflops / MFMA_PEAK_BF16_TFLOPS,
-                         "traffic": pmc_traffic(kname, G, S, args.blocks, fetch_factor=2.0),
+                         "traffic": pmc_traffic(kname, G, S, args.blocks, fetch_factor=2.0) if rows == G else None,
                          "kernel": "%s (%s; %d launches of %d boards, %.4f ms avg; %.0f%% of the step)" % (
-                             kname, kdesc, n_conv, G, conv_ms / max(n_conv, 1), 100.0 * conv_ms / (dt * 1e3)),
+                             kname, kdesc, n_conv, rows, conv_ms / max(n_conv, 1), 100.0 * conv_ms / (dt * 1e3)),
                          "flops_per_launch": conv_fl},
             "roofline_net": {"bound": "mfma", "achieved": net_tflops, "peak": MFMA_PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                              "frac": net_tflops / MFMA_PEAK_BF16_TFLOPS, "traffic": None,

@@ -102,6 +102,9 @@ _SIGNATURES = {
     "xq_engine_set_logit_columns": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "xq_engine_set_temperature": (C.c_int, [C.c_void_p, C.c_double, C.c_void_p, C.c_int]),
     "xq_engine_set_root_noise": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_uint64]),
+    "xq_engine_set_tree_reuse": (C.c_int, [C.c_void_p, C.c_int]),
+    "xq_engine_set_virtual_loss": (C.c_int, [C.c_void_p, C.c_int]),
+    "xq_engine_leaf_slots": (C.c_int, [C.c_void_p]),
     "xq_engine_read_root_priors": (C.c_int, [C.c_void_p, C.c_void_p]),
     "xq_engine_set_uniforms": (C.c_int, [C.c_void_p, C.c_void_p]),
     "xq_engine_set_roots": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -83,6 +83,14 @@ struct Eng {
     uint64_t noise_seed;
     // optional compact policy layout: logits rows hold only n_cols columns, col_map[move] = column
     const int16_t *col_map; int n_cols;
+    // tree root per game: always node 0 (fresh tree every ply, self_play.py:98) unless the opt-in
+    // tree reuse keeps the played child's subtree (extension)
+    uint16_t *root_node; int tree_reuse;
+    // virtual loss (opt-in extension): K = leaf_slots pending leaves per game and round instead of one
+    // (every leaf_* / priors / values array and the evaluator's rows are indexed by slot = g * K + k);
+    // nVl counts the pending visits through a node and is folded into PUCT as N + vl, W - vl
+    int vloss, leaf_slots;
+    uint8_t *nVl;
 };
 
 struct __align__(16) WaveLds {
@@ -224,26 +232,32 @@ __device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_floa
 
 // ---- tree primitives ---------------------------------------------------------------------
 struct Tree {
-    uint32_t *N; double *W; float *P; uint16_t *mv; uint16_t *first; uint8_t *nc; uint8_t *fl;
+    uint32_t *N; double *W; float *P; uint16_t *mv; uint16_t *first; uint8_t *nc; uint8_t *fl; uint8_t *vl;
 };
 __device__ __forceinline__ Tree tree_of(const Eng &E, int g)
 {
     size_t o = (size_t)g * E.ncap;
-    return Tree{ E.nN + o, E.nW + o, E.nP + o, E.nMove + o, E.nFirst + o, E.nNc + o, E.nFlags + o };
+    return Tree{ E.nN + o, E.nW + o, E.nP + o, E.nMove + o, E.nFirst + o, E.nNc + o, E.nFlags + o, E.nVl + o };
 }
 
 // self_play.py:40-59 — float32 stepwise PUCT (NumPy >= 2 scalar rules), first maximum wins
+template <bool VL>
 __device__ int select_child(const Tree &T, int node)
 {
     const int lane = XQ_LANE;
     const int first = T.first[node], nc = T.nc[node];
-    const float sq = (float)sqrt((double)T.N[node]);
+    const float sq = (float)sqrt((double)(T.N[node] + (VL ? (uint32_t)T.vl[node] : 0u)));
     float best = -INFINITY;
     int bi = 0x7fffffff;
     for (int c = lane; c < nc; c += 64) {
-        const uint32_t n = T.N[first + c];
-        const double w = T.W[first + c];
+        uint32_t n = T.N[first + c];
+        double w = T.W[first + c];
         const float p = T.P[first + c];
+        if (VL) {                                   // pending visits count as losses
+            const uint32_t v = T.vl[first + c];
+            n += v;
+            w -= (double)v;
+        }
         float q = n ? (float)(w / (double)n) : 0.0f;
         float t = 1.5f * p;
         t = t * sq;
@@ -262,11 +276,11 @@ __device__ int select_child(const Tree &T, int node)
 
 // self_play.py:70-80: `mult` sequential updates of value v at the node on level `depth`
 // (levels: 0 = root, i = path_node[i-1]); every ancestor alternates the sign.
-__device__ void backup(const Tree &T, const uint16_t *path_node, int depth, double v, int mult)
+__device__ void backup(const Tree &T, int root, const uint16_t *path_node, int depth, double v, int mult)
 {
     const int lane = XQ_LANE;
     if (lane <= depth) {
-        const int x = lane == 0 ? 0 : path_node[lane - 1];
+        const int x = lane == 0 ? root : path_node[lane - 1];
         const double sv = ((depth - lane) & 1) ? -v : v;
         double w = T.W[x];
         for (int i = 0; i < mult; i++) w += sv;
@@ -298,23 +312,40 @@ __device__ float gamma_sample(float alpha, uint64_t key)
     return g * powf(u01(key), 1.0f / alpha);
 }
 
+// P' = (1 - eps) P + eps * eta, eta ~ Dirichlet(alpha) over the n children of the root (lane j and
+// lane j + 64 hold children j and j + 64); the stream is keyed by (seed, game, ply)
+__device__ void root_noise(const Eng &E, int g, int ply, int n, float &p0, float &p1)
+{
+    const int lane = XQ_LANE;
+    const uint64_t base = E.noise_seed ^ mix64(((uint64_t)g << 20) ^ ((uint64_t)ply << 8));
+    float g0 = lane < n ? gamma_sample((float)E.noise_alpha, base + (uint64_t)lane * 1024u) : 0.f;
+    float g1 = lane + 64 < n ? gamma_sample((float)E.noise_alpha, base + (uint64_t)(lane + 64) * 1024u) : 0.f;
+    float gs_ = g0 + g1;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) gs_ += __shfl_xor(gs_, d, 64);
+    const float eps = (float)E.noise_eps;
+    p0 = (1.0f - eps) * p0 + eps * (g0 / gs_);
+    p1 = (1.0f - eps) * p1 + eps * (g1 / gs_);
+}
+
 // self_play.py:61-68 + 146-148: expand the pending leaf with its priors and apply its backups
-__device__ void consume_eval(const Eng &E, int g, WaveLds &L, const Tree &T, int eval_kind,
+template <bool VL>
+__device__ void consume_eval(const Eng &E, int g, int slot, WaveLds &L, const Tree &T, int root, int eval_kind,
                              const void *ev_a, const void *ev_v, int ply)
 {
     const int lane = XQ_LANE;
-    const int node = E.leaf_node[g];
+    const int node = E.leaf_node[slot];
     if (node == LEAF_NONE) return;
-    const int n = E.leaf_n[g], mult = E.leaf_mult[g], depth = E.leaf_depth[g];
-    const uint16_t *lm = E.leaf_moves + (size_t)g * MAXM;
+    const int n = E.leaf_n[slot], mult = E.leaf_mult[slot], depth = E.leaf_depth[slot];
+    const uint16_t *lm = E.leaf_moves + (size_t)slot * MAXM;
     double v;
     float p0 = 0.f, p1 = 0.f;
     const int m0 = lane < n ? lm[lane] : 0, m1 = lane + 64 < n ? lm[lane + 64] : 0;
     if (eval_kind == XQ_EVAL_PRIORS) {
-        const float *pr = reinterpret_cast<const float *>(ev_a) + (size_t)g * MAXM;
+        const float *pr = reinterpret_cast<const float *>(ev_a) + (size_t)slot * MAXM;
         if (lane < n) p0 = pr[lane];
         if (lane + 64 < n) p1 = pr[lane + 64];
-        v = reinterpret_cast<const double *>(ev_v)[g];
+        v = reinterpret_cast<const double *>(ev_v)[slot];
     } else {
         // neural_network.py:148-169: gather the legal logits, float32 softmax over them
         float x0 = -INFINITY, x1 = -INFINITY;
@@ -322,15 +353,15 @@ __device__ void consume_eval(const Eng &E, int g, WaveLds &L, const Tree &T, int
         const int c0 = (E.col_map && lane < n) ? E.col_map[m0] : m0;
         const int c1 = (E.col_map && lane + 64 < n) ? E.col_map[m1] : m1;
         if (eval_kind == XQ_EVAL_LOGITS_F32) {
-            const float *lg = reinterpret_cast<const float *>(ev_a) + (size_t)g * stride;
+            const float *lg = reinterpret_cast<const float *>(ev_a) + (size_t)slot * stride;
             if (lane < n) x0 = lg[c0];
             if (lane + 64 < n) x1 = lg[c1];
-            v = (double)reinterpret_cast<const float *>(ev_v)[g];
+            v = (double)reinterpret_cast<const float *>(ev_v)[slot];
         } else {
-            const uint16_t *lg = reinterpret_cast<const uint16_t *>(ev_a) + (size_t)g * stride;
+            const uint16_t *lg = reinterpret_cast<const uint16_t *>(ev_a) + (size_t)slot * stride;
             if (lane < n) x0 = bf16_to_f32(lg[c0]);
             if (lane + 64 < n) x1 = bf16_to_f32(lg[c1]);
-            v = (double)bf16_to_f32(reinterpret_cast<const uint16_t *>(ev_v)[g]);
+            v = (double)bf16_to_f32(reinterpret_cast<const uint16_t *>(ev_v)[slot]);
         }
         float mx = fmaxf(x0, x1);
 #pragma unroll
@@ -341,18 +372,7 @@ __device__ void consume_eval(const Eng &E, int g, WaveLds &L, const Tree &T, int
         for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d, 64);
         p0 = e0 / sum; p1 = e1 / sum;
     }
-    if (E.noise_eps > 0.0 && node == 0) {
-        // P' = (1 - eps) P + eps * eta, eta ~ Dirichlet(alpha) over the root's children
-        const uint64_t base = E.noise_seed ^ mix64(((uint64_t)g << 20) ^ ((uint64_t)ply << 8));
-        float g0 = lane < n ? gamma_sample((float)E.noise_alpha, base + (uint64_t)lane * 1024u) : 0.f;
-        float g1 = lane + 64 < n ? gamma_sample((float)E.noise_alpha, base + (uint64_t)(lane + 64) * 1024u) : 0.f;
-        float gs_ = g0 + g1;
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) gs_ += __shfl_xor(gs_, d, 64);
-        const float eps = (float)E.noise_eps;
-        p0 = (1.0f - eps) * p0 + eps * (g0 / gs_);
-        p1 = (1.0f - eps) * p1 + eps * (g1 / gs_);
-    }
+    if (E.noise_eps > 0.0 && node == root) root_noise(E, g, ply, n, p0, p1);
     const int first = (int)E.n_nodes[g];
     if (first + n <= E.ncap) {
         for (int h = 0; h < 2; h++) {
@@ -361,15 +381,20 @@ __device__ void consume_eval(const Eng &E, int g, WaveLds &L, const Tree &T, int
                 int x = first + j;
                 T.N[x] = 0; T.W[x] = 0.0; T.P[x] = h ? p1 : p0; T.mv[x] = (uint16_t)(h ? m1 : m0);
                 T.first[x] = 0; T.nc[x] = 0; T.fl[x] = 0;
+                if (VL) T.vl[x] = 0;
             }
         }
         if (lane == 0) { T.first[node] = (uint16_t)first; T.nc[node] = (uint8_t)n; E.n_nodes[g] = (uint32_t)(first + n); }
     }
-    if (lane < depth) L.path_node[lane] = E.leaf_path[(size_t)g * PATH_CAP + lane];
+    if (lane < depth) L.path_node[lane] = E.leaf_path[(size_t)slot * PATH_CAP + lane];
     wave_sync();
     mem_fence_wave();
-    backup(T, L.path_node, depth, v, mult);
-    if (lane == 0) E.leaf_node[g] = LEAF_NONE;
+    if (VL && lane <= depth) {                       // the pending visits of this leaf are real now
+        const int x = lane == 0 ? root : L.path_node[lane - 1];
+        T.vl[x] = (uint8_t)(T.vl[x] - mult);
+    }
+    backup(T, root, L.path_node, depth, v, mult);
+    if (lane == 0) E.leaf_node[slot] = LEAF_NONE;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -410,7 +435,9 @@ __global__ __launch_bounds__(64) void k_new_games(Eng E)
     gs.reason_count = 0; gs.rk = (int8_t)rk; gs.bk = (int8_t)bk; gs.nocap = 0; gs.cchk = 0; gs.n_hist = 0;
     gs.n_root = (uint8_t)n; gs.done = 0; gs.n_samples = 0; gs.error = 0; gs.n_plies = 0;
     store_gs(E.gs + g, gs);
-    if (lane == 0) { E.leaf_node[g] = LEAF_NONE; E.leaf_mult[g] = 0; }
+    const int K = E.leaf_slots;
+    for (int k = lane; k < K; k += 64) { E.leaf_node[(size_t)g * K + k] = LEAF_NONE; E.leaf_mult[(size_t)g * K + k] = 0; }
+    if (lane == 0) E.root_node[g] = 0;
 }
 
 // roots from caller-provided envs (one staged int8 board + int32 state row per game)
@@ -432,27 +459,29 @@ __global__ __launch_bounds__(64) void k_set_roots(Eng E, const int8_t *boards, c
     gs.nocap = (uint8_t)st[XQ_S_NO_CAPTURE]; gs.cchk = 0; gs.n_hist = 0; gs.n_root = (uint8_t)n;
     gs.done = (n == 0) ? 1 : 0; gs.n_samples = 0; gs.error = 0; gs.n_plies = 0;
     store_gs(E.gs + g, gs);
-    if (lane == 0) { E.leaf_node[g] = LEAF_NONE; E.leaf_mult[g] = 0; }
+    const int K = E.leaf_slots;
+    for (int k = lane; k < K; k += 64) { E.leaf_node[(size_t)g * K + k] = LEAF_NONE; E.leaf_mult[(size_t)g * K + k] = 0; }
+    if (lane == 0) E.root_node[g] = 0;
 }
 
-__device__ void record_leaf(const Eng &E, int g, WaveLds &L, const int8_t *bd, int side, int node,
+__device__ void record_leaf(const Eng &E, int slot, WaveLds &L, const int8_t *bd, int side, int node,
                             int depth, int mult, const uint16_t *moves, int n, void *planes, int fmt)
 {
     const int lane = XQ_LANE;
-    for (int j = lane; j < n; j += 64) E.leaf_moves[(size_t)g * MAXM + j] = moves[j];
-    if (lane < depth) E.leaf_path[(size_t)g * PATH_CAP + lane] = L.path_node[lane];
-    if (lane < 12) E.leaf_board[(size_t)g * 12 + lane] = pack_dword(bd, lane);
+    for (int j = lane; j < n; j += 64) E.leaf_moves[(size_t)slot * MAXM + j] = moves[j];
+    if (lane < depth) E.leaf_path[(size_t)slot * PATH_CAP + lane] = L.path_node[lane];
+    if (lane < 12) E.leaf_board[(size_t)slot * 12 + lane] = pack_dword(bd, lane);
     if (lane == 0) {
-        E.leaf_node[g] = (uint16_t)node; E.leaf_mult[g] = (uint8_t)mult; E.leaf_n[g] = (uint8_t)n;
-        E.leaf_depth[g] = (uint8_t)depth; E.leaf_side[g] = (int8_t)side;
+        E.leaf_node[slot] = (uint16_t)node; E.leaf_mult[slot] = (uint8_t)mult; E.leaf_n[slot] = (uint8_t)n;
+        E.leaf_depth[slot] = (uint8_t)depth; E.leaf_side[slot] = (int8_t)side;
     }
-    if (planes) write_planes(bd, side, planes, fmt, g);
+    if (planes) write_planes(bd, side, planes, fmt, slot);
 }
 
 // OCC = minimum waves per SIMD requested from the register allocator.  The kernel is a chain of
 // dependent global loads (tree walk) with ~1.6 k VALU per wave, i.e. latency-bound: occupancy is
 // the lever (PMC: 62 % of wave cycles in s_waitcnt at 3 waves/SIMD).
-template <int OCC>
+template <int OCC, bool VL>
 __global__ __launch_bounds__(64, OCC) void k_search_round(Eng E, int round, int batch_count, int eval_kind,
                                                           const void *ev_a, const void *ev_v, void *planes, int fmt)
 {
@@ -464,38 +493,75 @@ __global__ __launch_bounds__(64, OCC) void k_search_round(Eng E, int round, int 
     const GameS gs = load_gs(E.gs + g);
     if (gs.done) return;
     const Tree T = tree_of(E, g);
+    const int K = VL ? E.leaf_slots : 1;             // pending-leaf slots of this game: g * K + k
+    int root = 0;
 
     if (round == 0) {
-        if (lane == 0) {                             // fresh tree every ply (self_play.py:98)
-            T.N[0] = 0; T.W[0] = 0.0; T.P[0] = 0.f; T.mv[0] = 0; T.first[0] = 0; T.nc[0] = 0; T.fl[0] = 0;
-            E.n_nodes[g] = 1; E.leaf_node[g] = LEAF_NONE;
+        // tree reuse (opt-in): k_play_move left the played child as the root when it had been
+        // expanded; keep its subtree while a whole ply's expansions still fit the arena
+        if (E.tree_reuse) {
+            root = E.root_node[g];
+            if (root != 0 && (T.nc[root] == 0 || (int)E.n_nodes[g] + E.nrounds * K * MAXM > E.ncap)) root = 0;
+        }
+        if (root == 0) {
+            if (lane == 0) {                         // fresh tree every ply (self_play.py:98)
+                T.N[0] = 0; T.W[0] = 0.0; T.P[0] = 0.f; T.mv[0] = 0; T.first[0] = 0; T.nc[0] = 0; T.fl[0] = 0;
+                if (VL) T.vl[0] = 0;
+                E.n_nodes[g] = 1; E.root_node[g] = 0;
+            }
+            for (int k = lane; k < K; k += 64) E.leaf_node[(size_t)g * K + k] = LEAF_NONE;
+        } else if (E.noise_eps > 0.0) {              // the kept root gets this ply's noise on its stored priors
+            const int n = T.nc[root], first = T.first[root];
+            float p0 = lane < n ? T.P[first + lane] : 0.f, p1 = lane + 64 < n ? T.P[first + lane + 64] : 0.f;
+            root_noise(E, g, gs.n_plies, n, p0, p1);
+            if (lane < n) T.P[first + lane] = p0;
+            if (lane + 64 < n) T.P[first + lane + 64] = p1;
         }
         mem_fence_wave();
     } else {
-        consume_eval(E, g, L, T, eval_kind, ev_a, ev_v, gs.n_plies);
+        root = E.root_node[g];
+        for (int k = 0; k < K; k++)
+            consume_eval<VL>(E, g, g * K + k, L, T, root, eval_kind, ev_a, ev_v, gs.n_plies);
     }
 
     unpack_to_lds(E.board + (size_t)g * 12, L.root_bd);
     wave_sync();
 
     int sims_left = batch_count;
+    int nslot = 0;                                   // VL: slots handed out in this round
     while (sims_left > 0) {
         // ---- select (self_play.py:117-119); the tree is frozen unless a terminal leaf updates it
-        int node = 0, depth = 0;
+        int node = root, depth = 0;
         while (T.nc[node] != 0 && depth < PATH_CAP) {
-            const int child = select_child(T, node);
+            const int child = select_child<VL>(T, node);
             if (lane == 0) { L.path_node[depth] = (uint16_t)child; L.path_move[depth] = T.mv[child]; }
             node = child;
             depth++;
         }
         wave_sync();
         int flags = T.fl[node];
+        if (VL && !(flags & F_TERM) && T.vl[node] != 0) {
+            // this leaf is already waiting for the network in one of this round's slots: one more
+            // pending visit through the same path
+            const int mine = (lane < nslot && E.leaf_node[(size_t)g * K + lane] == node) ? 1 : 0;
+            const int k = __ffsll((unsigned long long)__ballot(mine)) - 1;
+            if (lane == 0 && k >= 0) E.leaf_mult[(size_t)g * K + k] += 1;
+            if (lane <= depth) { const int x = lane == 0 ? root : L.path_node[lane - 1]; T.vl[x] += 1; }
+            mem_fence_wave();
+            sims_left--;
+            continue;
+        }
         if (!(flags & F_TERM)) {
-            if (node == 0) {
+            if (node == root) {
                 // the root is never terminal (the driver checked legal moves, self_play.py:205-208)
-                record_leaf(E, g, L, L.root_bd, gs.side, 0, 0, sims_left, E.root_moves + (size_t)g * MAXM,
-                            gs.n_root, planes, fmt);
-                return;
+                record_leaf(E, g * K + nslot, L, L.root_bd, gs.side, root, 0, VL ? 1 : sims_left,
+                            E.root_moves + (size_t)g * MAXM, gs.n_root, planes, fmt);
+                if (!VL) return;
+                if (lane == 0) T.vl[root] += 1;
+                mem_fence_wave();
+                nslot++;
+                sims_left--;
+                continue;
             }
             // ---- replay the path on a copy of the root env (_copy_env, self_play.py:156-175)
             for (int s = lane; s < 24; s += 64)
@@ -530,8 +596,14 @@ __global__ __launch_bounds__(64, OCC) void k_search_round(Eng E, int round, int 
             const bool terminal = (mr.n_legal == 0) || (st.winner != WINNER_NONE);     // self_play.py:126
             if (!terminal) {
                 if (lane == 0) T.fl[node] = (uint8_t)flags;
-                record_leaf(E, g, L, L.bd, st.side, node, depth, sims_left, L.legal, mr.n_legal, planes, fmt);
-                return;
+                record_leaf(E, g * K + nslot, L, L.bd, st.side, node, depth, VL ? 1 : sims_left, L.legal, mr.n_legal,
+                            planes, fmt);
+                if (!VL) return;
+                if (lane <= depth) { const int x = lane == 0 ? root : L.path_node[lane - 1]; T.vl[x] += 1; }
+                mem_fence_wave();
+                nslot++;
+                sims_left--;
+                continue;
             }
             // self_play.py:128-133, value from the side to move at the leaf
             flags |= F_TERM;
@@ -540,7 +612,7 @@ __global__ __launch_bounds__(64, OCC) void k_search_round(Eng E, int round, int 
             if (lane == 0) T.fl[node] = (uint8_t)flags;
         }
         const double v = (flags & F_VAL_POS) ? 1.0 : ((flags & F_VAL_NEG) ? -1.0 : 0.0);
-        backup(T, L.path_node, depth, v, 1);                                           // self_play.py:135
+        backup(T, root, L.path_node, depth, v, 1);                                     // self_play.py:135
         sims_left--;
     }
 }
@@ -556,8 +628,8 @@ __device__ __forceinline__ uint32_t crc_byte(uint32_t crc, uint32_t b)
 __global__ __launch_bounds__(64) void k_hashnet(Eng E, int salt)
 {
     __shared__ WaveLds L;
-    const int g = blockIdx.x, lane = XQ_LANE;
-    if (E.gs[g].done || E.leaf_node[g] == LEAF_NONE) return;
+    const int g = blockIdx.x, lane = XQ_LANE;             // one block per pending-leaf slot
+    if (E.gs[g / E.leaf_slots].done || E.leaf_node[g] == LEAF_NONE) return;
     unpack_to_lds(E.leaf_board + (size_t)g * 12, L.bd);
     wave_sync();
     uint32_t crc = 0xffffffffu;
@@ -583,7 +655,13 @@ __global__ __launch_bounds__(64) void k_end_search(Eng E, int eval_kind, const v
     const GameS gs = load_gs(E.gs + g);
     if (gs.done) return;
     const Tree T = tree_of(E, g);
-    consume_eval(E, g, L, T, eval_kind, ev_a, ev_v, gs.n_plies);
+    const int root = E.root_node[g];
+    if (E.vloss) {
+        for (int k = 0; k < E.leaf_slots; k++)
+            consume_eval<true>(E, g, g * E.leaf_slots + k, L, T, root, eval_kind, ev_a, ev_v, gs.n_plies);
+    } else {
+        consume_eval<false>(E, g, g, L, T, root, eval_kind, ev_a, ev_v, gs.n_plies);
+    }
 }
 
 // NumPy float64 add.reduce (pairwise, 8 partial sums; n <= 128)
@@ -614,7 +692,8 @@ __global__ __launch_bounds__(64) void k_play_move(Eng E)
     GameS gs = load_gs(E.gs + g);
     if (gs.done) return;
     const Tree T = tree_of(E, g);
-    const int nc = T.nc[0], first = T.first[0];
+    const int root = E.root_node[g];
+    const int nc = T.nc[root], first = T.first[root];
     if (nc == 0) { gs.done = 1; store_gs(E.gs + g, gs); return; }       // self_play.py:216-217
 
     for (int j = lane; j < nc; j += 64) L.ibuf[j] = (int)T.N[first + j];
@@ -671,6 +750,8 @@ __global__ __launch_bounds__(64) void k_play_move(Eng E)
         return;
     }
     const int move = T.mv[first + pick];
+    if (E.tree_reuse && lane == 0)       // keep the played child's subtree if it was ever expanded
+        E.root_node[g] = (uint16_t)(T.nc[first + pick] != 0 ? first + pick : 0);
 
     MState st = to_mstate(gs);
     HistGlobal hist{ E.pos_hist + (size_t)g * PATH_CAP, E.chk_hist + (size_t)g * PATH_CAP, gs.n_hist, gs.n_hist, 0ull, 0 };
@@ -737,6 +818,22 @@ __global__ __launch_bounds__(64) void k_pack_samples(Eng E, xq_sample_record *re
             r->chosen = valid ? E.t_move[si] : 0;
         }
     }
+}
+
+// root children of every game (moves, visit counts, priors), zero-padded to 128
+__global__ __launch_bounds__(64) void k_root_children(Eng E, uint16_t *moves, int32_t *visits, float *priors, int32_t *n_child)
+{
+    const int g = blockIdx.x, lane = XQ_LANE;
+    const Tree T = tree_of(E, g);
+    const int root = E.root_node[g];
+    const int nc = T.nc[root], first = T.first[root];
+    for (int j = lane; j < MAXM; j += 64) {
+        const bool ok = j < nc;
+        if (moves) moves[(size_t)g * MAXM + j] = ok ? T.mv[first + j] : (uint16_t)0;
+        if (visits) visits[(size_t)g * MAXM + j] = ok ? (int32_t)T.N[first + j] : 0;
+        if (priors) priors[(size_t)g * MAXM + j] = ok ? T.P[first + j] : 0.f;
+    }
+    if (lane == 0 && n_child) n_child[g] = nc;
 }
 
 __global__ void k_count_active(const GameS *gs, int G, int *out)
@@ -975,6 +1072,10 @@ struct xq_engine {
     int *active_dev = nullptr;
     int8_t *stage_boards = nullptr;      // [G][90] staging for set_roots / read_leaves
     int32_t *stage_state = nullptr;      // [G][XQ_STATE_WORDS]
+    uint16_t *stage_rmoves = nullptr;    // [G][128] staging for read_root_visits / read_root_priors
+    int32_t *stage_rvisits = nullptr;    // [G][128]
+    float *stage_rpriors = nullptr;      // [G][128]
+    int32_t *stage_rn = nullptr;         // [G]
     // profiling
     bool prof = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_search, ev_play;
@@ -1014,6 +1115,7 @@ extern "C" int xq_engine_create(const xq_config *cfg, xq_engine **out)
     E.nrounds = nrounds; E.max_moves = cfg->max_moves; E.opponent_mode = cfg->opponent_mode;
     E.want_check = nrounds >= 12 ? 1 : 0;       // check_history only matters once 12 plies fit a path
     E.temperature = cfg->temperature;
+    E.leaf_slots = 1;
     const size_t G = (size_t)E.G, NC = (size_t)E.ncap;
     int bad = 0;
     bad |= dalloc(e, E.board, G * 12); bad |= dalloc(e, E.gs, G); bad |= dalloc(e, E.pos_hist, G * PATH_CAP);
@@ -1021,7 +1123,8 @@ extern "C" int xq_engine_create(const xq_config *cfg, xq_engine **out)
     bad |= dalloc(e, E.uniforms, G * XQ_MAX_PLIES);
     bad |= dalloc(e, E.nN, G * NC); bad |= dalloc(e, E.nW, G * NC); bad |= dalloc(e, E.nP, G * NC);
     bad |= dalloc(e, E.nMove, G * NC); bad |= dalloc(e, E.nFirst, G * NC); bad |= dalloc(e, E.nNc, G * NC);
-    bad |= dalloc(e, E.nFlags, G * NC); bad |= dalloc(e, E.n_nodes, G);
+    bad |= dalloc(e, E.nFlags, G * NC); bad |= dalloc(e, E.nVl, G * NC); bad |= dalloc(e, E.n_nodes, G);
+    bad |= dalloc(e, E.root_node, G);
     bad |= dalloc(e, E.leaf_node, G); bad |= dalloc(e, E.leaf_mult, G); bad |= dalloc(e, E.leaf_n, G);
     bad |= dalloc(e, E.leaf_depth, G); bad |= dalloc(e, E.leaf_moves, G * MAXM); bad |= dalloc(e, E.leaf_path, G * PATH_CAP);
     bad |= dalloc(e, E.leaf_board, G * 12); bad |= dalloc(e, E.leaf_side, G);
@@ -1032,6 +1135,8 @@ extern "C" int xq_engine_create(const xq_config *cfg, xq_engine **out)
     bad |= dalloc(e, E.step_reward, G * XQ_MAX_PLIES); bad |= dalloc(e, E.t_move, G * XQ_MAX_PLIES);
     bad |= dalloc(e, e->active_dev, 1); bad |= dalloc(e, e->stage_boards, G * 90);
     bad |= dalloc(e, e->stage_state, G * XQ_STATE_WORDS);
+    bad |= dalloc(e, e->stage_rmoves, G * MAXM); bad |= dalloc(e, e->stage_rvisits, G * MAXM);
+    bad |= dalloc(e, e->stage_rpriors, G * MAXM); bad |= dalloc(e, e->stage_rn, G);
     if (bad) {
         xq_engine_destroy(e);
         return fail(XQ_E_HIP, "hipMalloc failed while sizing the engine");
@@ -1142,14 +1247,105 @@ extern "C" int xq_engine_read_root_priors(xq_engine *e, float *priors /*[G][128]
 {
     if (!e || !priors) return fail(XQ_E_INVALID, "null argument");
     HIPCHK(hipSetDevice(e->cfg.device));
-    const size_t G = (size_t)e->E.G, NC = (size_t)e->E.ncap;
-    std::vector<float> P(G * (MAXM + 1));
-    std::vector<uint8_t> nc(G);
-    HIPCHK(hipMemcpy2DAsync(P.data(), (MAXM + 1) * 4, e->E.nP, NC * 4, (MAXM + 1) * 4, G, hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipMemcpy2DAsync(nc.data(), 1, e->E.nNc, NC, 1, G, hipMemcpyDeviceToHost, e->stream));
+    const size_t G = (size_t)e->E.G;
+    hipLaunchKernelGGL(k_root_children, dim3(e->E.G), dim3(64), 0, e->stream, e->E, (uint16_t *)nullptr, (int32_t *)nullptr,
+                       e->stage_rpriors, (int32_t *)nullptr);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(priors, e->stage_rpriors, G * MAXM * 4, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
-    for (size_t g = 0; g < G; g++)
-        for (int j = 0; j < MAXM; j++) priors[g * MAXM + j] = j < nc[g] ? P[g * (MAXM + 1) + 1 + j] : 0.f;
+    return 0;
+}
+
+// node arena for the extensions: one ply's worst case is nrounds * leaf_slots expansions of <= 128
+// children; tree reuse keeps a whole game's.  16-bit node indices cap it at 65,472 nodes (1.5 MB per
+// game); a leaf whose children no longer fit stays unexpanded (it is evaluated again when reached).
+static int grow_nodes(xq_engine *e)
+{
+    Eng &E = e->E;
+    long want = 1 + (long)E.nrounds * E.leaf_slots * MAXM;
+    if (E.tree_reuse) want = 1 + (want - 1) * (long)(E.max_moves < XQ_MAX_PLIES ? E.max_moves : XQ_MAX_PLIES);
+    if (want > 65472) want = 65472;
+    want = (want + 63) / 64 * 64;
+    if (want <= E.ncap) return 0;
+    HIPCHK(hipStreamSynchronize(e->stream));
+    const size_t G = (size_t)E.G, NC = (size_t)want;
+    int bad = 0;
+    bad |= dalloc(e, E.nN, G * NC); bad |= dalloc(e, E.nW, G * NC); bad |= dalloc(e, E.nP, G * NC);
+    bad |= dalloc(e, E.nMove, G * NC); bad |= dalloc(e, E.nFirst, G * NC); bad |= dalloc(e, E.nNc, G * NC);
+    bad |= dalloc(e, E.nFlags, G * NC); bad |= dalloc(e, E.nVl, G * NC);
+    if (bad) return fail(XQ_E_HIP, "hipMalloc failed while sizing the node arena");
+    E.ncap = (int)want;
+    return 0;
+}
+
+// opt-in extension (no counterpart in the reference): keep the played child's subtree as the next
+// ply's tree.  Re-sizes the node arena for a whole game's expansions (16-bit node indices: 65,472
+// nodes = 1.4 MB per game); call before xq_engine_new_games / xq_engine_set_roots.
+extern "C" int xq_engine_set_tree_reuse(xq_engine *e, int enable)
+{
+    if (!e) return fail(XQ_E_INVALID, "null engine");
+    HIPCHK(hipSetDevice(e->cfg.device));
+    Eng &E = e->E;
+    E.tree_reuse = enable ? 1 : 0;
+    if (int rc = grow_nodes(e)) return rc;
+    HIPCHK(hipMemsetAsync(E.root_node, 0, (size_t)E.G * 2, e->stream));
+    HIPCHK(hipMemsetAsync(E.n_nodes, 0, (size_t)E.G * 4, e->stream));
+    return 0;
+}
+
+// opt-in extension (no counterpart in the reference, whose rounds of 8 simulations all reach the same
+// leaf): virtual loss.  Every simulation of a round counts as a pending loss along its path, so the
+// round's simulations spread over up to leaf_batch distinct leaves, each evaluated once.  The
+// pending-leaf arrays, xq_engine_priors_ptr / values_ptr and the evaluator's rows (input planes,
+// logits, values) then hold leaf_batch slots per game: row = game * leaf_batch + slot.
+// Call before xq_engine_new_games / xq_engine_set_roots.
+extern "C" int xq_engine_set_virtual_loss(xq_engine *e, int enable)
+{
+    if (!e) return fail(XQ_E_INVALID, "null engine");
+    HIPCHK(hipSetDevice(e->cfg.device));
+    Eng &E = e->E;
+    const int K = enable ? E.leaf_batch : 1;
+    if (K > 64) return fail(XQ_E_INVALID, "virtual loss needs leaf_batch <= 64 (one lane per pending slot)");
+    if (K != E.leaf_slots) {
+        HIPCHK(hipStreamSynchronize(e->stream));
+        const size_t S = (size_t)E.G * (size_t)K;
+        int bad = 0;
+        bad |= dalloc(e, E.leaf_node, S); bad |= dalloc(e, E.leaf_mult, S); bad |= dalloc(e, E.leaf_n, S);
+        bad |= dalloc(e, E.leaf_depth, S); bad |= dalloc(e, E.leaf_moves, S * MAXM); bad |= dalloc(e, E.leaf_path, S * PATH_CAP);
+        bad |= dalloc(e, E.leaf_board, S * 12); bad |= dalloc(e, E.leaf_side, S);
+        bad |= dalloc(e, E.priors, S * MAXM); bad |= dalloc(e, E.values, S);
+        if (bad) return fail(XQ_E_HIP, "hipMalloc failed while sizing the pending-leaf slots");
+        E.leaf_slots = K;
+        HIPCHK(hipMemsetAsync(E.leaf_node, 0xff, S * 2, e->stream));        // LEAF_NONE
+    }
+    E.vloss = enable ? 1 : 0;
+    return grow_nodes(e);
+}
+
+extern "C" int xq_engine_leaf_slots(xq_engine *e) { return e ? e->E.leaf_slots : 0; }
+
+// diagnostic only: per game, nodes in the arena and the sum of pending (virtual-loss) visits
+__global__ void k_tree_stats(Eng E, int32_t *n_nodes, int32_t *vl_sum)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= E.G) return;
+    const int n = (int)E.n_nodes[g];
+    int sum = 0;
+    for (int i = 0; i < n; i++) sum += E.nVl[(size_t)g * E.ncap + i];
+    n_nodes[g] = n;
+    vl_sum[g] = sum;
+}
+extern "C" int xq_engine_debug_tree_stats(xq_engine *e, int32_t *n_nodes_host, int32_t *vl_sum_host)
+{
+    if (!e || !n_nodes_host || !vl_sum_host) return fail(XQ_E_INVALID, "null argument");
+    HIPCHK(hipSetDevice(e->cfg.device));
+    const size_t G = (size_t)e->E.G;
+    hipLaunchKernelGGL(k_tree_stats, dim3((e->E.G + 63) / 64), dim3(64), 0, e->stream, e->E, e->stage_rvisits,
+                       e->stage_rvisits + G);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(n_nodes_host, e->stage_rvisits, G * 4, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpyAsync(vl_sum_host, e->stage_rvisits + G, G * 4, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
     return 0;
 }
 
@@ -1243,14 +1439,17 @@ extern "C" int xq_engine_search_round(xq_engine *e, int round, int eval_kind, co
         if (ev) HIPCHK(hipEventRecord(ev->first, e->stream));
     }
     const int fmt = planes ? e->cfg.planes_format : XQ_PLANES_NONE;
-    switch (g_search_occ) {
-    case 3: hipLaunchKernelGGL(k_search_round<3>, dim3(e->E.G), dim3(64), 0, e->stream, e->E, round, batch, eval_kind, ev_a, ev_v, planes, fmt); break;
-    case 4: hipLaunchKernelGGL(k_search_round<4>, dim3(e->E.G), dim3(64), 0, e->stream, e->E, round, batch, eval_kind, ev_a, ev_v, planes, fmt); break;
-    case 5: hipLaunchKernelGGL(k_search_round<5>, dim3(e->E.G), dim3(64), 0, e->stream, e->E, round, batch, eval_kind, ev_a, ev_v, planes, fmt); break;
-    case 6: hipLaunchKernelGGL(k_search_round<6>, dim3(e->E.G), dim3(64), 0, e->stream, e->E, round, batch, eval_kind, ev_a, ev_v, planes, fmt); break;
-    case 8: hipLaunchKernelGGL(k_search_round<8>, dim3(e->E.G), dim3(64), 0, e->stream, e->E, round, batch, eval_kind, ev_a, ev_v, planes, fmt); break;
-    default: hipLaunchKernelGGL(k_search_round<4>, dim3(e->E.G), dim3(64), 0, e->stream, e->E, round, batch, eval_kind, ev_a, ev_v, planes, fmt); break;
+#define XQ_LAUNCH_SEARCH(OCC, VLB) hipLaunchKernelGGL((k_search_round<OCC, VLB>), dim3(e->E.G), dim3(64), 0, e->stream, e->E, \
+                                                    round, batch, eval_kind, ev_a, ev_v, planes, fmt)
+    if (e->E.vloss) XQ_LAUNCH_SEARCH(4, true);
+    else switch (g_search_occ) {
+    case 3: XQ_LAUNCH_SEARCH(3, false); break;
+    case 5: XQ_LAUNCH_SEARCH(5, false); break;
+    case 6: XQ_LAUNCH_SEARCH(6, false); break;
+    case 8: XQ_LAUNCH_SEARCH(8, false); break;
+    default: XQ_LAUNCH_SEARCH(4, false); break;
     }
+#undef XQ_LAUNCH_SEARCH
     HIPCHK(hipGetLastError());
     if (ev) HIPCHK(hipEventRecord(ev->second, e->stream));
     return 0;
@@ -1260,7 +1459,7 @@ extern "C" int xq_engine_eval_hashnet(xq_engine *e, int salt)
 {
     if (!e) return fail(XQ_E_INVALID, "null engine");
     HIPCHK(hipSetDevice(e->cfg.device));
-    hipLaunchKernelGGL(k_hashnet, dim3(e->E.G), dim3(64), 0, e->stream, e->E, salt);
+    hipLaunchKernelGGL(k_hashnet, dim3(e->E.G * e->E.leaf_slots), dim3(64), 0, e->stream, e->E, salt);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -1334,6 +1533,7 @@ extern "C" int xq_engine_read_leaves(xq_engine *e, int8_t *boards, int32_t *play
                                      int32_t *mult)
 {
     if (!e) return fail(XQ_E_INVALID, "null engine");
+    if (e->E.leaf_slots != 1) return fail(XQ_E_INVALID, "host-side evaluators see one leaf per game: not available with virtual loss");
     HIPCHK(hipSetDevice(e->cfg.device));
     const size_t G = (size_t)e->E.G;
     std::vector<uint32_t> pb(G * 12);
@@ -1360,6 +1560,7 @@ extern "C" int xq_engine_read_leaves(xq_engine *e, int8_t *boards, int32_t *play
 extern "C" int xq_engine_write_priors(xq_engine *e, const float *priors, const double *values)
 {
     if (!e || !priors || !values) return fail(XQ_E_INVALID, "null argument");
+    if (e->E.leaf_slots != 1) return fail(XQ_E_INVALID, "host-side evaluators see one leaf per game: not available with virtual loss");
     HIPCHK(hipSetDevice(e->cfg.device));
     const size_t G = (size_t)e->E.G;
     HIPCHK(hipMemcpyAsync(e->E.priors, priors, G * MAXM * 4, hipMemcpyHostToDevice, e->stream));
@@ -1372,25 +1573,14 @@ extern "C" int xq_engine_read_root_visits(xq_engine *e, uint16_t *moves, int32_t
 {
     if (!e || !moves || !visits || !n_child) return fail(XQ_E_INVALID, "null argument");
     HIPCHK(hipSetDevice(e->cfg.device));
-    const size_t G = (size_t)e->E.G, NC = (size_t)e->E.ncap;
-    // root children occupy nodes [first, first+nc) with first == 1 when expanded
-    std::vector<uint8_t> nc(G);
-    std::vector<uint16_t> first(G);
-    HIPCHK(hipMemcpy2DAsync(nc.data(), 1, e->E.nNc, NC, 1, G, hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipMemcpy2DAsync(first.data(), 2, e->E.nFirst, NC * 2, 2, G, hipMemcpyDeviceToHost, e->stream));
-    std::vector<uint32_t> N(G * (MAXM + 1));
-    std::vector<uint16_t> mv(G * (MAXM + 1));
-    HIPCHK(hipMemcpy2DAsync(N.data(), (MAXM + 1) * 4, e->E.nN, NC * 4, (MAXM + 1) * 4, G, hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipMemcpy2DAsync(mv.data(), (MAXM + 1) * 2, e->E.nMove, NC * 2, (MAXM + 1) * 2, G, hipMemcpyDeviceToHost, e->stream));
+    const size_t G = (size_t)e->E.G;
+    hipLaunchKernelGGL(k_root_children, dim3(e->E.G), dim3(64), 0, e->stream, e->E, e->stage_rmoves, e->stage_rvisits,
+                       (float *)nullptr, e->stage_rn);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(moves, e->stage_rmoves, G * MAXM * 2, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpyAsync(visits, e->stage_rvisits, G * MAXM * 4, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpyAsync(n_child, e->stage_rn, G * 4, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
-    for (size_t g = 0; g < G; g++) {
-        n_child[g] = nc[g];
-        for (int j = 0; j < MAXM; j++) {
-            const bool ok = j < nc[g] && first[g] == 1;
-            moves[g * MAXM + j] = ok ? mv[g * (MAXM + 1) + 1 + j] : 0;
-            visits[g * MAXM + j] = ok ? (int32_t)N[g * (MAXM + 1) + 1 + j] : 0;
-        }
-    }
     return 0;
 }
 

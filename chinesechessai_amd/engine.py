@@ -101,7 +101,7 @@ class TorchNetEvaluator:
 
     def bind(self, engine):
         torch = self.torch
-        G = engine.n_games
+        G = engine.n_rows                                       # one row per pending-leaf slot
         if self.channels_last:
             self.storage = torch.zeros((G, 10, 9, 16), dtype=self.dtype, device="cuda")
             self.x = self.storage.permute(0, 3, 1, 2)            # logical NCHW, channels-last strides
@@ -118,7 +118,7 @@ class TorchNetEvaluator:
         return self.storage.data_ptr()
 
     def evaluate(self, engine):
-        G = engine.n_games
+        G = engine.n_rows
         step = self.chunk or G
         for s in range(0, G, step):
             self.inet(self.x[s:s + step], out_logits=self.logits[s:s + step], out_values=self.values[s:s + step])
@@ -184,6 +184,7 @@ class SelfPlayEngine:
         self.rounds = self.L.xq_engine_rounds_per_move(h)
         self.priors_ptr = self.L.xq_engine_priors_ptr(h)
         self.values_ptr = self.L.xq_engine_values_ptr(h)
+        self.n_rows = n_games                                   # evaluator rows: n_games * leaf slots
         if stream is not None:
             _lib.check(self.L.xq_engine_set_stream(h, C.c_void_p(stream)))
         if temperature >= 0.01 and temperature != 1.0:
@@ -246,12 +247,38 @@ class SelfPlayEngine:
         """Per-ply temperature (extension; the reference uses one temperature per game)."""
         tab = None
         if temperature >= 0.01 and temperature != 1.0:
-            tab = np.ascontiguousarray(np.arange(self.sims + 1, dtype=np.int64) ** (1.0 / temperature), dtype=np.float64)
+            top = 65536 if getattr(self, "tree_reuse", False) else self.sims + 1     # carried visits exceed sims
+            tab = np.ascontiguousarray(np.arange(top, dtype=np.int64) ** (1.0 / temperature), dtype=np.float64)
         _lib.check(self.L.xq_engine_set_temperature(self.h, float(temperature), _lib.ptr(tab), 0 if tab is None else len(tab)))
 
     def set_root_noise(self, alpha, epsilon, seed=0):
         """Dirichlet root noise (extension, BASELINE C5): root priors (1-eps) P + eps Dir(alpha)."""
         _lib.check(self.L.xq_engine_set_root_noise(self.h, float(alpha), float(epsilon), int(seed)))
+
+    def set_tree_reuse(self, enable=True):
+        """Keep the played move's subtree as the next ply's tree (extension; the reference builds a
+        fresh tree every ply).  Call before new games are started."""
+        _lib.check(self.L.xq_engine_set_tree_reuse(self.h, 1 if enable else 0))
+        self.tree_reuse = bool(enable)
+        self.set_temperature(self.temperature)             # counts ** (1/T) table must cover carried visits
+
+    def set_virtual_loss(self, enable=True):
+        """A round's simulations spread over up to leaf_batch distinct leaves, each evaluated once
+        (extension; the reference's rounds all reach one leaf).  The evaluator then works on
+        n_rows = n_games * leaf_batch rows.  Call before new games are started and before an
+        evaluator is bound."""
+        _lib.check(self.L.xq_engine_set_virtual_loss(self.h, 1 if enable else 0))
+        self.n_rows = self.n_games * self.L.xq_engine_leaf_slots(self.h)
+        self.priors_ptr = self.L.xq_engine_priors_ptr(self.h)
+        self.values_ptr = self.L.xq_engine_values_ptr(self.h)
+
+    def tree_stats(self):
+        """(nodes in each game's arena, pending virtual-loss visits) — diagnostic."""
+        fn = self.L.xq_engine_debug_tree_stats
+        fn.argtypes, fn.restype = [C.c_void_p, C.c_void_p, C.c_void_p], C.c_int
+        n, v = np.zeros(self.n_games, np.int32), np.zeros(self.n_games, np.int32)
+        _lib.check(fn(self.h, _lib.ptr(n), _lib.ptr(v)))
+        return n, v
 
     def root_priors(self):
         p = np.zeros((self.n_games, _lib.MAX_MOVES), np.float32)

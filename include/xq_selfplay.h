@@ -142,6 +142,17 @@ int  xq_engine_set_logit_columns(xq_engine *e, const int16_t *map_host, int n_co
 int  xq_engine_set_temperature(xq_engine *e, double temperature, const double *table_host, int n);
 /* Dirichlet root noise: root priors become (1-eps) P + eps Dir(alpha); eps = 0 (default) disables */
 int  xq_engine_set_root_noise(xq_engine *e, double alpha, double epsilon, uint64_t seed);
+/* Tree reuse: the subtree of the played move becomes the next ply's tree (visit counts, values and
+ * priors carried over; the reference builds a fresh tree every ply, self_play.py:98).  0 (default)
+ * disables.  Re-sizes the node arena to a whole game's expansions; call before new_games/set_roots. */
+int  xq_engine_set_tree_reuse(xq_engine *e, int enable);
+/* Virtual loss: a round's simulations count as pending losses along their paths and spread over up
+ * to leaf_batch distinct leaves (the reference's rounds all reach one leaf, Appendix A10).  The
+ * evaluator then sees leaf_batch rows per game: row = game * leaf_batch + slot, for the input planes,
+ * the logits / values it returns and xq_engine_priors_ptr / values_ptr; unused slots are ignored.
+ * Not available to the host-side read_leaves / write_priors path.  Call before new_games/set_roots. */
+int  xq_engine_set_virtual_loss(xq_engine *e, int enable);
+int  xq_engine_leaf_slots(xq_engine *e);          /* evaluator rows per game: 1, or leaf_batch */
 /* priors stored on the root's children after the root was expanded, [G][128] */
 int  xq_engine_read_root_priors(xq_engine *e, float *priors_host);
 

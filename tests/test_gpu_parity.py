@@ -856,6 +856,262 @@ def test_search_extensions_are_opt_in_and_statistically_sound(L):
         assert sorted(pi)[-1] == 1.0 and sum(pi) == 1.0
 
 
+def test_tree_reuse_is_opt_in_and_consistent(L):
+    """Tree reuse (extension; the reference builds a fresh tree every ply): the
+    played child's subtree becomes the next ply's tree.  No oracle, so invariants: (1) off by default
+    and switching it off again restores the reference games; (2) deterministic; (3) every played
+    move is legal and the outcome is the rules oracle's when the moves are replayed on it; (4) the
+    root's children carry their visits over: sum of child visits == sims - 8 on a fresh tree (the
+    first round lands on the root) and == carried + sims on a kept tree, where carried is the
+    played child's own child-visit sum at the previous ply... checked through the stored sample
+    counts: the sum never drops below sims - 8 and exceeds it on most plies after the first."""
+    from chinesechessai_amd.engine import HashNetEvaluator, SelfPlayEngine
+    from oracle import xq_oracle as xo
+    S, NG = 24, 48
+    seeds = np.arange(900, 900 + NG, dtype=np.uint32)
+    ev = HashNetEvaluator()
+
+    def run(reuse):
+        eng = SelfPlayEngine(NG, sims=S)
+        if reuse is not None:
+            eng.set_tree_reuse(reuse)
+        bt = eng.play(ev, seeds)
+        eng.close()
+        return bt
+
+    base, off, on1, on2 = run(None), run(False), run(True), run(True)
+    for k in ("chosen", "winner", "reason", "n_plies", "s_counts"):
+        assert np.array_equal(getattr(base, k), getattr(off, k)), k
+        assert np.array_equal(getattr(on1, k), getattr(on2, k)), k
+    for g in range(NG):                                     # reference behaviour when off
+        rc, og = xo.self_play_game(900 + g, S)
+        assert list(og.t_move[:og.n_plies]) == base.chosen[g, :int(base.n_plies[g])].tolist()
+    assert not np.array_equal(base.chosen, on1.chosen)
+    kept = fresh = 0
+    for g in range(NG):
+        env = xo.OracleEnv()
+        env.reset()
+        n = int(on1.n_plies[g])
+        for i in range(n):
+            legal = env.legal_moves()
+            mv = int(on1.chosen[g, i])
+            assert mv in legal, (g, i)
+            k = int(on1.s_n[g, i])
+            assert on1.s_moves[g, i, :k].tolist() == legal, (g, i)
+            tot = int(on1.s_counts[g, i, :k].sum())
+            assert tot >= S - 8, (g, i, tot)
+            if i > 0:
+                kept += tot > S - 8
+                fresh += tot == S - 8
+            env.make_move(mv)
+        w = int(env.e.winner)
+        assert int(on1.winner[g]) == (0 if w == xo.WINNER_NONE else w), g
+    assert kept > 4 * fresh, (kept, fresh)                 # the sampled move almost always had been expanded
+
+
+def _vl_search_mirror(S, leaf_batch=8):
+    """Test-side restatement (Python, NumPy float32 PUCT as the reference's select_child) of one
+    MCTS.search from the start position WITH virtual loss as the engine defines it: a pending visit
+    counts as N + 1, W - 1 on every node of its path; a round's pending leaves are expanded and
+    backed up in the order they were reached.  Rules and the evaluator: the oracle env / HashNet."""
+    import zlib
+    from oracle import xq_oracle as xo
+
+    class Node:
+        __slots__ = ("N", "W", "P", "mv", "ch", "term", "val", "vl")
+
+        def __init__(self, P=np.float32(0), mv=0):
+            self.N, self.W, self.P, self.mv, self.ch, self.term, self.val, self.vl = 0, 0.0, P, mv, [], False, 0.0, 0
+
+    def hashnet(board, player, moves):
+        h0 = zlib.crc32(board.astype(np.int8).tobytes() + bytes([player & 0xff]))
+        pri = []
+        for mv in moves:
+            f, t = divmod(mv, 90)
+            h = zlib.crc32(bytes([f // 9, f % 9, t // 9, t % 9]), h0)
+            pri.append(np.float32(((h >> 8) % 64 + 1) / 1024))
+        return pri, ((h0 >> 4) % 65 - 32) / 64
+
+    def select(node):
+        sq = np.float32(np.sqrt(np.float64(node.N + node.vl)))
+        best, bi = None, -1
+        for i, c in enumerate(node.ch):
+            n, w = c.N + c.vl, c.W - float(c.vl)
+            q = np.float32(w / n) if n else np.float32(0)
+            t = np.float32(1.5) * c.P
+            t = t * sq
+            t = t / np.float32(1 + n)
+            sc = q + t
+            if best is None or sc > best:
+                best, bi = sc, i
+        return node.ch[bi]
+
+    def backup(root, path, v, mult):
+        depth = len(path)
+        for lvl in range(depth + 1):
+            x = root if lvl == 0 else path[lvl - 1]
+            sv = -v if ((depth - lvl) & 1) else v
+            for _ in range(mult):
+                x.W += sv
+            x.N += mult
+
+    root = Node()
+    pending = []
+
+    def consume():
+        for node, path, mult, moves, pri, val in pending:
+            node.ch = [Node(p, m) for p, m in zip(pri, moves)]
+            for x in [root] + path:
+                x.vl -= mult
+            backup(root, path, val, mult)
+        pending.clear()
+
+    done = 0
+    while done < S:
+        batch = min(leaf_batch, S - done)
+        consume()
+        for _ in range(batch):
+            node, path = root, []
+            while node.ch:
+                node = select(node)
+                path.append(node)
+            if not node.term and node.vl:
+                for e in pending:
+                    if e[0] is node:
+                        e[2] += 1
+                for x in [root] + path:
+                    x.vl += 1
+                continue
+            if not node.term:
+                env = xo.OracleEnv()
+                env.reset()
+                for x in path:
+                    env.make_move(x.mv)
+                legal = env.legal_moves()
+                w = int(env.e.winner)
+                if legal and w == xo.WINNER_NONE:
+                    side = int(env.e.current_player)
+                    pri, val = hashnet(env.board().reshape(90), side, legal)
+                    pending.append([node, list(path), 1, legal, pri, val])
+                    for x in [root] + path:
+                        x.vl += 1
+                    continue
+                node.term = True
+                side = int(env.e.current_player)
+                node.val = 1.0 if w == side else (-1.0 if w == -side else 0.0)
+            backup(root, path, node.val, 1)
+        done += batch
+    consume()
+    assert root.vl == 0
+    return [c.mv for c in root.ch], [c.N for c in root.ch], root
+
+
+def test_virtual_loss_is_opt_in_and_matches_its_restatement(L):
+    """Virtual loss (extension; the reference freezes the tree inside a round,
+    Appendix A10).  Off by default (every parity test above runs without it).  On: (1) one search
+    from the start position equals a Python restatement of the same rule, visit for visit, for
+    S = 16, 24, 50; (2) no pending visits are left after a search and the rounds now expand several
+    leaves (arena grows by far more than one expansion per round); (3) whole games are
+    deterministic, play legal moves only and end as the rules oracle says; (4) the host-callback
+    evaluator path refuses to run with it."""
+    from chinesechessai_amd import _lib
+    from chinesechessai_amd.engine import CallbackEvaluator, HashNetEvaluator, SelfPlayEngine
+    from oracle import xq_oracle as xo
+    ev = HashNetEvaluator()
+    for S in (16, 24, 50):
+        eng = SelfPlayEngine(4, sims=S)
+        eng.set_virtual_loss(True)
+        assert eng.n_rows == 4 * 8
+        eng.new_games(np.arange(4, dtype=np.uint32))
+        eng.search(ev)
+        moves, visits, n = eng.root_visits()
+        nodes, vl = eng.tree_stats()
+        eng.close()
+        mm, mv, root = _vl_search_mirror(S)
+        assert n[0] == len(mm) and moves[0, :n[0]].tolist() == mm
+        assert visits[0, :n[0]].tolist() == mv, (S, visits[0, :n[0]].tolist(), mv)
+        assert (visits == visits[0]).all() and (vl == 0).all()
+        rounds = (S + 7) // 8
+        assert nodes[0] > 1 + 44 * 2 * (rounds - 1)             # > 2 expansions per round after the first
+    S, NG = 24, 32
+    seeds = np.arange(1300, 1300 + NG, dtype=np.uint32)
+
+    def run():
+        eng = SelfPlayEngine(NG, sims=S)
+        eng.set_virtual_loss(True)
+        bt = eng.play(ev, seeds)
+        eng.close()
+        return bt
+
+    a, b = run(), run()
+    for k in ("chosen", "winner", "reason", "n_plies", "s_counts"):
+        assert np.array_equal(getattr(a, k), getattr(b, k)), k
+    for g in range(NG):
+        env = xo.OracleEnv()
+        env.reset()
+        for i in range(int(a.n_plies[g])):
+            legal = env.legal_moves()
+            k = int(a.s_n[g, i])
+            assert a.s_moves[g, i, :k].tolist() == legal and int(a.chosen[g, i]) in legal, (g, i)
+            assert int(a.s_counts[g, i, :k].sum()) == S - 8, (g, i)      # the first round still lands on the root
+            env.make_move(int(a.chosen[g, i]))
+        w = int(env.e.winner)
+        assert int(a.winner[g]) == (0 if w == xo.WINNER_NONE else w), g
+
+    class Net:
+        def predict_batch(self, rows):
+            return [({m: 1.0 / len(legal) for m in legal}, 0.0) for _, _, legal in rows]
+    eng = SelfPlayEngine(2, sims=16)
+    eng.set_virtual_loss(True)
+    eng.new_games(np.arange(2, dtype=np.uint32))
+    cb = CallbackEvaluator(Net())
+    cb.bind(eng)
+    with pytest.raises(_lib.XqError):
+        eng.search(cb)
+    eng.close()
+
+
+def test_extensions_with_the_real_network(L):
+    """Tree reuse + virtual loss + root noise together on the bf16 network path (8 evaluator rows per
+    game): games complete without errors, only legal moves are played (rules oracle replay), pi of
+    every sample sums to 1 and the run is repeatable."""
+    import torch
+    from chinesechessai_amd.engine import SelfPlayEngine, TorchNetEvaluator
+    from chinesechessai_amd.neural_network import ChessNet
+    from oracle import xq_oracle as xo
+    torch.manual_seed(3)
+    net = ChessNet(num_blocks=2).cuda().eval()
+    NG, S = 48, 24
+    seeds = np.arange(77, 77 + NG, dtype=np.uint32)
+
+    def run():
+        ev = TorchNetEvaluator(net)
+        eng = SelfPlayEngine(NG, sims=S, planes_format=ev.planes_format, max_moves=30)
+        eng.set_tree_reuse(True)
+        eng.set_virtual_loss(True)
+        eng.set_root_noise(0.3, 0.25, seed=5)
+        assert eng.n_rows == NG * 8
+        bt = eng.play(ev, seeds)
+        nodes, vl = eng.tree_stats()
+        eng.close()
+        assert (vl == 0).all() and nodes.max() < 65472
+        return bt
+
+    a, b = run(), run()
+    assert np.array_equal(a.chosen, b.chosen) and np.array_equal(a.s_counts, b.s_counts)
+    assert int(a.error.sum()) == 0 and (a.n_plies == 30).all()
+    for g in range(NG):
+        env = xo.OracleEnv()
+        env.reset()
+        for i in range(int(a.n_plies[g])):
+            legal = env.legal_moves()
+            k = int(a.s_n[g, i])
+            assert a.s_moves[g, i, :k].tolist() == legal and int(a.chosen[g, i]) in legal, (g, i)
+            env.make_move(int(a.chosen[g, i]))
+        for _, pi, _ in a.game_data(g):
+            assert abs(sum(pi.values()) - 1.0) < 1e-9
+
+
 def test_reachable_policy_columns_give_the_same_priors(L, golden_dir):
     """Opt-in compact policy head (2,294 of 8,100 columns) vs the full head on the network fixture
     positions: identical legal-move priors up to the bf16 GEMM's shape-dependent rounding
