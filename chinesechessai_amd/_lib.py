@@ -161,6 +161,8 @@ def lib():
             fn.argtypes = args
         L.xq_conv3x3_set_variant.argtypes = [C.c_int]          # diagnostic switch, not in the public header
         L.xq_conv3x3_set_variant.restype = None
+        L.xq_tower_set_variant.argtypes = [C.c_int]            # diagnostic switch: MFMA shape of the trunk kernel
+        L.xq_tower_set_variant.restype = None
         _lib = L
     return _lib
 

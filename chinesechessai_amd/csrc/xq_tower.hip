@@ -389,7 +389,335 @@ __global__ __launch_bounds__(256, 2) void k_tower(TowerArgs A)
     stamp(61);
 }
 
+
+// ------------------------------------------------------------------------------------------
+// The same trunk on v_mfma_f32_16x16x32_bf16.  Same workgroup, wave tile (96 pixels x 64 channels)
+// and LDS budget; 24 accumulators of 4 registers instead of 6 of 16.  Why: under the board's power
+// cap the chip holds a higher clock on this shape (bare loops: 2.18 vs 1.96 PFLOP/s, tools/
+// bench_tower.py; MI355X_MICROARCH.md "DVFS give-back" item 7) at equal cycles per FLOP.
+// Differences that follow from the shape:
+//   * lane = (r16 = lane & 15, q = lane >> 4): a fragment is row r16 of its tile, 16-B chunk q of the
+//     32-channel K-step; ds_read_b128 serves lanes in groups that mix q = 0 / 1 (2 / 3), so the
+//     activation rows are swizzled by chunk ^ ((pixel & 7) << 1) (conflict-free for every tap shift);
+//   * K-step = 32 channels: a weight stage (64 cin) is 2 K-steps; the stage barrier opens the second
+//     one, whose 24 MFMAs cover the DMA refill and the next stage's first fragments;
+//   * MFMAs run pixel-tile-major: the 4 weight fragments of a K-step stay in registers (double
+//     buffered), the 6 activation fragments roll through 3 registers sets two tiles ahead;
+//   * the input conv packs two taps (2 x 16 planes) into one K-step and stages all its weights
+//     (36,864 B, over the still unused activation rows) at once: no barriers inside it.
+// ------------------------------------------------------------------------------------------
+// LDS by absolute byte offset (the kernel has no static __shared__, so the dynamic allocation starts
+// at 0): spares the per-access add of the relocatable base that `extern __shared__` arrays cost
+#define XQ_AS3 __attribute__((address_space(3)))
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wint-to-pointer-cast"
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+__device__ __forceinline__ bf16x8 lds_ld128(int off) { return *(const XQ_AS3 bf16x8 *)(uint32_t)off; }
+__device__ __forceinline__ f32x4 lds_ldf4(int off) { return *(const XQ_AS3 f32x4 *)(uint32_t)off; }
+__device__ __forceinline__ void lds_st64(int off, uint2 v) { *(XQ_AS3 u32x2 *)(uint32_t)off = u32x2{ v.x, v.y }; }
+__device__ __forceinline__ void lds_st128(int off, uint4 v) { *(XQ_AS3 u32x4 *)(uint32_t)off = u32x4{ v.x, v.y, v.z, v.w }; }
+__device__ __forceinline__ void dma16_abs(const void *gsrc, int lds_off)
+{
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc, (XQ_AS3 void *)(uint32_t)lds_off, 16, 0, 0);
+}
+__device__ __forceinline__ void dma16_buf_abs(rsrc_t rsrc, int voffset, int soffset, int lds_off)
+{
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (XQ_AS3 void *)(uint32_t)lds_off, 16, voffset, soffset, 0, 0);
+}
+#pragma clang diagnostic pop
+
+template <bool STAMP>
+__global__ __launch_bounds__(256, 2) void k_tower16(TowerArgs A)
+{
+    constexpr int ACT0 = 2 * WBUF_BYTES, ZROW = ACT0 + 2 * ACT_BYTES, BIAS = ZROW + 256;   // bias: [2][128] f32
+
+    auto stamp = [&](int slot) {
+        if constexpr (STAMP) {
+            const unsigned long long t = __builtin_amdgcn_s_memtime();
+            if (threadIdx.x == 0) A.stamps[(size_t)blockIdx.x * 64 + slot] = t;
+            if (slot == 0 || slot == 61) {
+                const unsigned long long rt = __builtin_amdgcn_s_memrealtime();
+                if (threadIdx.x == 0) A.stamps[(size_t)blockIdx.x * 64 + (slot == 0 ? 62 : 63)] = rt;
+            }
+        }
+    };
+    stamp(0);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wb_ = wave >> 1, hc = wave & 1;                         // board in workgroup, channel half
+    const int board = blockIdx.x * 2 + wb_;
+    const bool board_ok = board < A.G;
+    const int act_off = ACT0 + wb_ * ACT_BYTES;
+    const int r16 = lane & 15, q = lane >> 4;
+
+    // tap validity of the 6 pixels of this lane (pixel tile nt: pixel nt * 16 + r16), 9 bits each
+    uint32_t vm[2] = { 0, 0 };
+#pragma unroll
+    for (int nt = 0; nt < 6; nt++) {
+        const int o = nt * 16 + r16;
+        uint32_t m = 0;
+        if (o < PIX) {
+            const int yy = o / 9, xx = o % 9;
+#pragma unroll
+            for (int t = 0; t < 9; t++) {
+                const int dy = t / 3 - 1, dx = t % 3 - 1;
+                if (yy + dy >= 0 && yy + dy < 10 && xx + dx >= 0 && xx + dx < 9) m |= 1u << t;
+            }
+        }
+        vm[nt / 3] |= m << ((nt % 3) * 9);
+    }
+
+    f32x4 acc[4][6];
+    uint2 xres[4][6];                     // block input (residual), packed bf16 in accumulator layout
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+            for (int nt = 0; nt < 6; nt++)
+#pragma unroll
+                for (int i = 0; i < 4; i++) acc[mt][nt][i] = 0.f;
+    };
+
+    // ---------------------------------------------------------------- input conv (16 -> 128)
+    // LDS during this phase: [0, 36864) all 9 tap slices [128 cout][16 ch] (32-B rows, linear);
+    // each board's planes (90 x 32 B, linear) in the LAST 2,880 B of its activation region
+    const int pl_off = act_off + ACT_BYTES - PIX * 32;
+    if (tid < 16) lds_st128(ZROW + tid * 16, make_uint4(0, 0, 0, 0));
+    if (wave == 1 && lane < 32) dma16_abs(A.bias + lane * 4, BIAS);
+#pragma unroll
+    for (int j = 0; j < 9; j++) {
+        const int piece = wave * 9 + j;
+        dma16_abs(reinterpret_cast<const uint8_t *>(A.w1) + piece * 1024 + lane * 16, piece * 1024);
+    }
+    if (board_ok) {
+        const uint8_t *src = reinterpret_cast<const uint8_t *>(A.planes) + (size_t)board * PIX * 32;
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int q0 = (j * 2 + hc) * 64, idx = q0 + lane;
+            if (idx < PIX * 2) dma16_abs(src + idx * 16, pl_off + q0 * 16);
+        }
+    }
+    zero_acc();
+    __syncthreads();
+#pragma unroll
+    for (int pair = 0; pair < 5; pair++) {                           // K-step = taps (2 pair, 2 pair + 1) x 16 planes
+        const int tap = 2 * pair + (q >> 1);
+        const bool tap_real = tap < 9;
+        const int tp = tap_real ? tap : 8;
+        const int off = (tp / 3 - 1) * 9 + (tp % 3 - 1);
+        bf16x8 bf[6], af[4];
+#pragma unroll
+        for (int nt = 0; nt < 6; nt++) {
+            const bool ok = tap_real && ((vm[nt / 3] >> ((nt % 3) * 9 + tp)) & 1u);
+            const int sp = nt * 16 + r16 + off;
+            bf[nt] = lds_ld128(ok ? pl_off + sp * 32 + (q & 1) * 16 : ZROW + (q & 1) * 16);
+        }
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++)
+            af[mt] = lds_ld128((tp * COUT + hc * 64 + mt * 16 + r16) * 32 + (q & 1) * 16);
+#pragma unroll
+        for (int nt = 0; nt < 6; nt++)
+#pragma unroll
+            for (int mt = 0; mt < 4; mt++)
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mt], bf[nt], acc[mt][nt], 0, 0, 0);
+    }
+    __syncthreads();                                                 // every wave is done with planes and tap slices
+    stamp(1);
+
+    // weight stream of the 128-channel layers: as in k_tower (stage g -> buffer g & 1)
+    const int nlayers = 2 * A.nblocks, nstages = nlayers * 18;
+    const rsrc_t wrsrc = make_rsrc(A.wt, nlayers * 9 * COUT * COUT * 2);
+    int wsrc[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int i = (wave * 4 + j) * 64 + lane, row = i >> 3, cp = i & 7;
+        wsrc[j] = row * 256 + ((cp ^ ((row >> 1) & 7)) * 16);
+    }
+    auto stage_piece = [&](int g, int buf, int j) {
+        const int soff = (g >> 1) * (COUT * COUT * 2) + (g & 1) * 128;
+        dma16_buf_abs(wrsrc, wsrc[j], soff, buf * WBUF_BYTES + (wave * 4 + j) * 1024);
+    };
+    // A fragment (weight tile mt, K-step kk of a stage): abase ^ (kk << 6), + mt * 2048
+    const int abase = (hc * 64 + r16) * 128 + ((q ^ ((r16 >> 1) & 7)) << 4);
+    auto load_a1 = [&](bf16x8 &af, int mt, int sl, int kk) {
+        af = lds_ld128((abase ^ (kk << 6)) + sl * WBUF_BYTES + mt * 2048);
+    };
+    // B fragment (pixel tile nt, K-step ks of the 128 channels): a0[nt] ^ (ks << 6)
+    auto tap_addr = [&](int (&a0)[6], int tap) {
+        const int off = (tap / 3 - 1) * 9 + (tap % 3 - 1);
+#pragma unroll
+        for (int nt = 0; nt < 6; nt++) {
+            const bool ok = (vm[nt / 3] >> ((nt % 3) * 9 + tap)) & 1u;
+            const int sp = nt * 16 + r16 + off;
+            a0[nt] = ok ? act_off + sp * 256 + ((q ^ ((sp & 7) << 1)) << 4) : ZROW + (q << 4);
+        }
+    };
+    auto load_b1 = [&](bf16x8 &bf, int a, int ks) { bf = lds_ld128(a ^ (ks << 6)); };
+
+    // epilogue: acc + bias [+ residual] -> ReLU -> bf16 -> LDS rows in place (+ keep as next residual)
+    auto epilogue = [&](int lb, auto add_res, auto keep_res) {     // lb: LDS offset of this layer's 128 biases
+        int sb[6];
+#pragma unroll
+        for (int nt = 0; nt < 6; nt++) {
+            const int p = nt * 16 + r16 < PIX ? nt * 16 + r16 : 0;
+            sb[nt] = act_off + p * 256 + (q & 1) * 8 + (((hc * 8 + (q >> 1)) ^ ((p & 7) << 1)) << 4);
+            asm volatile("" : "+v"(sb[nt]));
+        }
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++) {
+            const f32x4 b4 = lds_ldf4(lb + (hc * 64 + mt * 16 + 4 * q) * 4);
+#pragma unroll
+            for (int nt = 0; nt < 6; nt++) {
+                float v0 = acc[mt][nt][0] + b4[0], v1 = acc[mt][nt][1] + b4[1];
+                float v2 = acc[mt][nt][2] + b4[2], v3 = acc[mt][nt][3] + b4[3];
+                if constexpr (decltype(add_res)::value) {
+                    const uint2 r = xres[mt][nt];
+                    v0 += bf16_lo(r.x); v1 += bf16_hi(r.x); v2 += bf16_lo(r.y); v3 += bf16_hi(r.y);
+                }
+                const uint2 pk = make_uint2(relu_bf16x2(pack_bf16x2(v0, v1)), relu_bf16x2(pack_bf16x2(v2, v3)));
+                if constexpr (decltype(keep_res)::value) xres[mt][nt] = pk;
+                if (nt < 5 || r16 < PIX - 80) lds_st64(sb[nt] ^ (mt << 5), pk);
+            }
+        }
+    };
+    using yes = std::integral_constant<bool, true>;
+    using no = std::integral_constant<bool, false>;
+
+    if (nstages > 0) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) { stage_piece(0, 0, j); stage_piece(1, 1, j); }
+        if (wave == 1 && lane < 32) dma16_abs(A.bias + 128 + lane * 4, BIAS + 512);
+    }
+    epilogue(BIAS, no{}, yes{});
+    __syncthreads();
+    stamp(2);
+
+    // ---------------------------------------------------------------- residual tower
+    bf16x8 fa[2][4], fb[3];                                          // weights: K-step parity; activations: rolling
+    if (nstages > 0) {
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++) load_a1(fa[0][mt], mt, 0, 0);
+    }
+    for (int layer = 0; layer < nlayers; layer++) {
+        zero_acc();
+        if (wave == 1 && lane < 32 && layer + 1 < nlayers)          // next layer's bias, slot (layer + 2) & 1
+            dma16_abs(A.bias + (size_t)(layer + 2) * 128 + lane * 4, BIAS + (layer & 1) * 512);
+        int a0[6];
+        tap_addr(a0, 0);
+        load_b1(fb[0], a0[0], 0);
+        load_b1(fb[1], a0[1], 0);
+        for (int tap = 0; tap < 9; tap++) {
+            int a0n[6];
+            tap_addr(a0n, tap < 8 ? tap + 1 : 8);
+#pragma unroll
+            for (int ks = 0; ks < 4; ks++) {                        // 4 K-steps of 32 channels = 2 weight stages
+                const int sl = ks >> 1, kk = ks & 1, cur = ks & 1;
+                const int g = layer * 18 + tap * 2 + sl;
+                if (kk == 1) __syncthreads();                        // stage st+1 has landed, nobody reads buffer sl any more
+#pragma unroll
+                for (int n = 0; n < 6; n++) {                        // pixel tile n: 4 MFMAs
+                    // activation fragment two tiles ahead (this K-step, or the next one's first two)
+                    const int tb = n + 2;
+                    if (tb < 6) load_b1(fb[tb % 3], a0[tb], ks);
+                    else if (ks < 3) load_b1(fb[tb % 3], a0[tb - 6], ks + 1);
+                    else load_b1(fb[tb % 3], a0n[tb - 6], 0);
+                    // next K-step's weight fragments, one per tile; the refill of this buffer two stages ahead
+                    if (n < 4) {
+                        if (kk == 0) load_a1(fa[cur ^ 1][n], n, sl, 1);
+                        else {
+                            load_a1(fa[cur ^ 1][n], n, sl ^ 1, 0);
+                            stage_piece(g + 2 < nstages ? g + 2 : nstages - 1, sl, n);
+                        }
+                    }
+#pragma unroll
+                    for (int mt = 0; mt < 4; mt++)
+                        acc[mt][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[cur][mt], fb[n % 3], acc[mt][n], 0, 0, 0);
+                    // issue order inside the tile: reads, first MFMA, DMA piece, the other MFMAs
+                    if (n < 4) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    else __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    if (kk == 1 && n < 4) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+                }
+            }
+#pragma unroll
+            for (int nt = 0; nt < 6; nt++) a0[nt] = a0n[nt];
+        }
+        if (layer < 28) stamp(3 + 2 * layer);
+        if (layer & 1) epilogue(BIAS + ((layer + 1) & 1) * 512, yes{}, yes{});
+        else epilogue(BIAS + ((layer + 1) & 1) * 512, no{}, no{});
+        __syncthreads();
+        if (layer < 28) stamp(4 + 2 * layer);
+    }
+
+    // ---------------------------------------------------------------- heads (1x1, 128 -> 32 + 8)
+    {
+        const uint8_t *src = reinterpret_cast<const uint8_t *>(A.wh);     // [64][256 B], chunk ^ ((row & 7) << 1)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int q0 = (wave * 4 + j) * 64, idx = q0 + lane, row = idx >> 4, cp = idx & 15;
+            dma16_abs(src + row * 256 + ((cp ^ ((row & 7) << 1)) * 16), q0 * 16);
+        }
+    }
+    f32x4 hacc[2][6];
+#pragma unroll
+    for (int m = 0; m < 2; m++)
+#pragma unroll
+        for (int nt = 0; nt < 6; nt++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) hacc[m][nt][i] = 0.f;
+    __syncthreads();
+    const int nm = hc == 0 ? 2 : 1;                                  // policy: rows 0..31, value: rows 32..47
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) {
+        bf16x8 hb[6], ha[2];
+#pragma unroll
+        for (int nt = 0; nt < 6; nt++) {
+            const int p = nt * 16 + r16 < PIX ? nt * 16 + r16 : 0;
+            hb[nt] = lds_ld128(act_off + p * 256 + (((ks * 4 + q) ^ ((p & 7) << 1)) << 4));
+        }
+#pragma unroll
+        for (int m = 0; m < 2; m++) {
+            const int row = hc * 32 + m * 16 + r16;
+            ha[m] = lds_ld128(row * 256 + (((ks * 4 + q) ^ ((row & 7) << 1)) << 4));
+        }
+#pragma unroll
+        for (int m = 0; m < 2; m++)
+            if (m < nm)
+#pragma unroll
+                for (int nt = 0; nt < 6; nt++)
+                    hacc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ha[m], hb[nt], hacc[m][nt], 0, 0, 0);
+    }
+    stamp(60);
+    if (!board_ok) { stamp(61); return; }
+    uint8_t *Pb = reinterpret_cast<uint8_t *>(A.P) + (size_t)board * PIX * 64;
+    uint8_t *Vb = reinterpret_cast<uint8_t *>(A.V) + (size_t)board * PIX * 16;
+#pragma unroll
+    for (int m = 0; m < 2; m++) {
+        if (m >= nm) break;
+        const int c0 = hc * 32 + m * 16 + 4 * q;                     // head channel of element 0
+        const f32x4 b4 = *reinterpret_cast<const f32x4 *>(A.bh + c0);
+#pragma unroll
+        for (int nt = 0; nt < 6; nt++) {
+            const int p = nt * 16 + r16;
+            if (p < PIX && (hc == 0 || q < 2)) {                     // value head: channels 32..39 only
+                const float v0 = hacc[m][nt][0] + b4[0], v1 = hacc[m][nt][1] + b4[1];
+                const float v2 = hacc[m][nt][2] + b4[2], v3 = hacc[m][nt][3] + b4[3];
+                const uint2 pk = make_uint2(relu_bf16x2(pack_bf16x2(v0, v1)), relu_bf16x2(pack_bf16x2(v2, v3)));
+                if (hc == 0) *reinterpret_cast<uint2 *>(Pb + p * 64 + c0 * 2) = pk;
+                else *reinterpret_cast<uint2 *>(Vb + p * 16 + (c0 - 32) * 2) = pk;
+            }
+        }
+    }
+    stamp(61);
+}
+
 }  // namespace
+
+static int g_tower_variant = 1;     // 1 = k_tower16 (v_mfma_f32_16x16x32_bf16), 0 = k_tower (32x32x16)
+// diagnostic switch (not part of the public ABI): both kernels compute the same function
+extern "C" void xq_tower_set_variant(int v) { g_tower_variant = v ? 1 : 0; }
 
 template <bool STAMP>
 static int launch_tower(void *stream, const void *planes, const void *w1, const void *wt, const void *bias, const void *wh,
@@ -401,6 +729,8 @@ static int launch_tower(void *stream, const void *planes, const void *w1, const 
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tower<STAMP>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                LDS_BYTES) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tower16<STAMP>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 LDS_BYTES) != hipSuccess)
             return XQ_E_HIP;
         attr_set = true;
@@ -408,7 +738,10 @@ static int launch_tower(void *stream, const void *planes, const void *w1, const 
     TowerArgs a{ (const uint16_t *)planes, (const uint16_t *)w1, (const uint16_t *)wt, (const float *)bias,
                  (const uint16_t *)wh, (const float *)bh, (uint16_t *)policy_out, (uint16_t *)value_out, n_boards, n_blocks,
                  (unsigned long long *)stamps };
-    hipLaunchKernelGGL(k_tower<STAMP>, dim3((n_boards + 1) / 2), dim3(256), LDS_BYTES, reinterpret_cast<hipStream_t>(stream), a);
+    if (g_tower_variant)
+        hipLaunchKernelGGL(k_tower16<STAMP>, dim3((n_boards + 1) / 2), dim3(256), LDS_BYTES, reinterpret_cast<hipStream_t>(stream), a);
+    else
+        hipLaunchKernelGGL(k_tower<STAMP>, dim3((n_boards + 1) / 2), dim3(256), LDS_BYTES, reinterpret_cast<hipStream_t>(stream), a);
     return hipGetLastError() == hipSuccess ? 0 : XQ_E_HIP;
 }
 
@@ -511,10 +844,51 @@ __global__ __launch_bounds__(256, 2) void k_mfma_probe(const uint32_t *seed, con
 }
 }  // namespace
 
+// the same bare loop on v_mfma_f32_16x16x32_bf16 (24 accumulators of 4 registers: the same 96 x 64
+// output tile per wave, the same FLOPs per iteration): which shape the chip clocks higher on
+namespace {
+__global__ __launch_bounds__(256, 2) void k_mfma_probe16(const uint32_t *seed, float *out, int iters)
+{
+    const int tid = threadIdx.x, lane = tid & 63;
+    uint32_t s = seed[lane] + blockIdx.x * 2654435761u + tid * 40503u;
+    auto rnd = [&]() { s = s * 1664525u + 1013904223u; return s; };
+    bf16x8 a[4], b[6];
+    for (int i = 0; i < 8; i++) {
+        for (int m = 0; m < 4; m++) a[m][i] = (__bf16)(((int)(rnd() >> 9) % 2048 - 1024) * (1.0f / 1024.0f));
+        for (int n = 0; n < 6; n++) {
+            const float v = ((int)(rnd() >> 9) % 2048 - 1024) * (1.0f / 1024.0f);
+            b[n][i] = (__bf16)(v > 0.f ? v : 0.f);
+        }
+    }
+    f32x4 acc[4][6];
+    for (int m = 0; m < 4; m++) for (int n = 0; n < 6; n++) for (int i = 0; i < 4; i++) acc[m][n][i] = 0.f;
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int u = 0; u < 2; u++)
+#pragma unroll
+            for (int n = 0; n < 6; n++)
+#pragma unroll
+                for (int m = 0; m < 4; m++) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m], b[n], acc[m][n], 0, 0, 0);
+    }
+    float t = 0.f;
+    for (int m = 0; m < 4; m++) for (int n = 0; n < 6; n++) for (int i = 0; i < 4; i++) t += acc[m][n][i];
+    if (t == 123.456f) out[0] = t;
+    if (blockIdx.x == 0 && tid == 0) {
+        out[1] = (float)(__builtin_amdgcn_s_memtime() - c0);
+        out[2] = (float)(__builtin_amdgcn_s_memrealtime() - r0);
+    }
+}
+}  // namespace
+
 extern "C" int xq_mfma_probe(void *stream, const void *seed64_dev, const void *weights_dev, void *out_dev, int n_workgroups,
                              int iters, int mode)
 {
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (mode == 16) {       // 48 MFMAs of 16x16x32 per iteration = the FLOPs of 24 of 32x32x16
+        hipLaunchKernelGGL(k_mfma_probe16, dim3(n_workgroups), dim3(256), 0, st, (const uint32_t *)seed64_dev, (float *)out_dev, iters);
+        return hipGetLastError() == hipSuccess ? 0 : XQ_E_HIP;
+    }
     const int lds_bytes = mode ? 80128 : 0;
     if (mode == 0) hipLaunchKernelGGL(k_mfma_probe<0>, dim3(n_workgroups), dim3(256), 0, st, (const uint32_t *)seed64_dev, (const uint8_t *)weights_dev, (float *)out_dev, iters);
     else {

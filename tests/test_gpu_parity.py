@@ -535,7 +535,11 @@ def test_single_launch_trunk_equals_per_layer_kernels(L):
     from chinesechessai_amd.neural_network import ChessNet, InferenceNet
     from chinesechessai_amd import _lib
     st = torch.cuda.current_stream().cuda_stream
-    for blocks, G in ((6, 37), (1, 2), (2, 129), (0, 5), (6, 1)):
+    # both MFMA shapes of the trunk kernel: 1 = v_mfma_f32_16x16x32_bf16 (default), 0 = 32x32x16; only the
+    # latter accumulates in the per-layer kernels' order (bit-identical without residual blocks)
+    for variant, blocks, G in ((1, 6, 37), (1, 1, 2), (1, 2, 129), (1, 0, 5), (1, 6, 1), (1, 3, 64),
+                               (0, 6, 37), (0, 0, 5), (0, 2, 3)):
+        L.xq_tower_set_variant(variant)
         torch.manual_seed(10 + blocks)
         net = ChessNet(num_blocks=blocks).eval()
         for m in net.modules():                                  # non-trivial running statistics
@@ -559,7 +563,7 @@ def test_single_launch_trunk_equals_per_layer_kernels(L):
         torch.cuda.synchronize()
         assert P0.abs().max().item() > 0
         assert (P1[G] == 9.0).all() and (V1[G] == 9.0).all()
-        if blocks == 0:
+        if blocks == 0 and variant == 0:
             assert torch.equal(P1[:G].view(torch.int16), P0.view(torch.int16)), (blocks, G)
             assert torch.equal(V1[:G].view(torch.int16), V0.view(torch.int16)), (blocks, G)
         # fp32 torch chain on the same bf16 weights, bf16 rounding between layers
@@ -585,6 +589,7 @@ def test_single_launch_trunk_equals_per_layer_kernels(L):
         lb, vb = inet_f(x)
         assert (la.float() - lb.float()).abs().max().item() <= 0.05 * max(1.0, la.float().abs().max().item())
         assert (va.float() - vb.float()).abs().max().item() <= 0.05
+    L.xq_tower_set_variant(1)
     assert L.xq_tower_nhwc_bf16(st, None, None, None, None, None, None, None, None, 4, 6) == -1
 
 

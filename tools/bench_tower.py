@@ -36,8 +36,13 @@ def timeit(fn, it=20):
 
 
 fl = 2.0 * G * 90 * (16 * 9 * 128 + 2 * blocks * 128 * 9 * 128 + 128 * 40)
-ms = timeit(lambda: L.xq_tower_nhwc_bf16(*args))
-print("k_tower G=%d blocks=%d: %.3f ms  %.1f TFLOP/s" % (G, blocks, ms, fl / ms / 1e9))
+for variant in (0, 1, 0, 1):
+    L.xq_tower_set_variant(variant)
+    ms = timeit(lambda: L.xq_tower_nhwc_bf16(*args))
+    print("k_tower%s G=%d blocks=%d: %.3f ms  %.1f TFLOP/s" % ("16 (16x16x32)" if variant else " (32x32x16)", G, blocks, ms, fl / ms / 1e9))
+variant = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+L.xq_tower_set_variant(variant)
+print("stamps: variant %d" % variant)
 
 fn = L.xq_tower_debug_stamps
 fn.argtypes = [C.c_void_p] * 9 + [C.c_int, C.c_int, C.c_void_p]
@@ -76,7 +81,9 @@ probe.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_i
 seed = torch.randint(0, 2 ** 31 - 1, (64,), dtype=torch.int32, device="cuda")
 wts = torch.randint(-2 ** 31, 2 ** 31 - 1, (216 * 16384 // 4,), dtype=torch.int32, device="cuda")
 outp = torch.zeros(4, device="cuda")
-for mode, name in ((0, "registers only"), (1, "+ LDS fragment reads"), (2, "+ LDS reads + LDS-DMA weight stream")):
+for mode, name in ((0, "32x32x16, registers only"), (16, "16x16x32, registers only"), (0, "32x32x16, registers only"),
+                   (16, "16x16x32, registers only"), (1, "32x32x16 + LDS fragment reads"),
+                   (2, "32x32x16 + LDS reads + LDS-DMA weight stream")):
     iters = 20000
     ms = timeit(lambda: probe(st, seed.data_ptr(), wts.data_ptr(), outp.data_ptr(), 512, iters, mode), it=3)
     fl_p = 512 * 4 * iters * 24 * 2.0 * 32 * 32 * 16
