@@ -79,6 +79,16 @@ __device__ __forceinline__ void dma16(const void *gsrc, void *lds_wave_base)
 // LDS-DMA through a buffer resource: address = SGPR resource + per-lane 32-bit voffset + scalar
 // soffset, i.e. no per-piece 64-bit VALU address arithmetic.
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
+// A workgroup barrier that also publishes LDS-DMA data: each wave first drains ITS OWN pieces
+// (s_waitcnt vmcnt(0)), then the barrier makes every wave's pieces visible.  The wait is explicit:
+// the compiler's fence lowering for __syncthreads() does not promise a vmcnt wait at workgroup scope
+// (it was missing at one of the stage barriers of k_tower16).
+__device__ __forceinline__ void barrier_dma()
+{
+    __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0), expcnt / lgkmcnt untouched
+    __syncthreads();
+}
+
 __device__ __forceinline__ rsrc_t make_rsrc(const void *base, int bytes)
 {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), /*stride*/ 0, bytes, /*flags*/ 0x00020000);
@@ -197,7 +207,7 @@ __global__ __launch_bounds__(NB * 128, 2) void k_conv3x3_b(const uint16_t *__res
 #pragma unroll
             for (int i = 0; i < 16; i++) acc[mt][nt][i] = 0.f;
 
-    __syncthreads();
+    barrier_dma();
     stamp(1);
 
     // residual rows for the epilogue: requested a few stages before the end of the main loop so
@@ -266,7 +276,7 @@ __global__ __launch_bounds__(NB * 128, 2) void k_conv3x3_b(const uint16_t *__res
                     for (int nt = 0; nt < 3; nt++)
                         acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[cur][mt], bfr[cur][nt], acc[mt][nt], 0, 0, 0);
             }
-            if (ABLATE != 1 && ABLATE != 3) __syncthreads();
+            if (ABLATE != 1 && ABLATE != 3) barrier_dma();
             if constexpr (STAMP) { if (st < 18) stamp(2 + st); }
         }
     }
@@ -302,7 +312,7 @@ __global__ __launch_bounds__(NB * 128, 2) void k_conv3x3_b(const uint16_t *__res
         }
     }
     stamp(21);
-    __syncthreads();
+    barrier_dma();
     stamp(22);
     if (board_ok) {
         // each wave streams half of its board's rows out (coalesced 16-B chunks), residual + ReLU
@@ -377,7 +387,7 @@ __global__ __launch_bounds__(HNB * 64, 2) void k_heads(const uint16_t *__restric
         for (int nt = 0; nt < 3; nt++)
 #pragma unroll
             for (int i = 0; i < 16; i++) acc[mt][nt][i] = 0.f;
-    __syncthreads();
+    barrier_dma();
 #pragma unroll
     for (int kk = 0; kk < 8; kk++) {
         const int c = kk * 2 + h;

@@ -53,6 +53,16 @@ __device__ __forceinline__ void dma16(const void *gsrc, void *lds_wave_base)
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
                                      (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
 }
+// A workgroup barrier that also publishes LDS-DMA data: each wave first drains ITS OWN pieces
+// (s_waitcnt vmcnt(0)), then the barrier makes every wave's pieces visible.  The wait is explicit:
+// the compiler's fence lowering for __syncthreads() does not promise a vmcnt wait at workgroup scope
+// (it was missing at one of the stage barriers of k_tower16).
+__device__ __forceinline__ void barrier_dma()
+{
+    __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0), expcnt / lgkmcnt untouched
+    __syncthreads();
+}
+
 __device__ __forceinline__ rsrc_t make_rsrc(const void *base, int bytes)
 {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, bytes, 0x00020000);
@@ -166,7 +176,7 @@ __global__ __launch_bounds__(256, 2) void k_tower(TowerArgs A)
         }
     }
     zero_acc();
-    __syncthreads();
+    barrier_dma();
     for (int tap = 0; tap < 9; tap++) {
         const int buf = tap & 1;
         if (tap + 1 < 9) stage_w1(tap + 1, buf ^ 1);
@@ -185,7 +195,7 @@ __global__ __launch_bounds__(256, 2) void k_tower(TowerArgs A)
             af[mt] = *reinterpret_cast<const bf16x8 *>(wbuf + buf * 4096 + row * 32 + ((h ^ ((row >> 3) & 1)) * 16));
         }
         mfma6(af, bf);
-        __syncthreads();
+        barrier_dma();
     }
     stamp(1);
 
@@ -269,7 +279,7 @@ __global__ __launch_bounds__(256, 2) void k_tower(TowerArgs A)
         if (wave == 1 && lane < 32) dma16(A.bias + 128 + lane * 4, lbias + 128);
     }
     epilogue(lbias, no{}, yes{});
-    __syncthreads();
+    barrier_dma();
     stamp(2);
 
     // ---------------------------------------------------------------- residual tower
@@ -303,7 +313,7 @@ __global__ __launch_bounds__(256, 2) void k_tower(TowerArgs A)
                     // end of a stage: every wave has its last fragments of this buffer in registers,
                     // the next stage's pieces have landed -> fetch the next stage's first fragments and
                     // refill this buffer two stages ahead while this K-step's MFMAs run
-                    __syncthreads();
+                    barrier_dma();
                     const int g = layer * 18 + tap * 2 + sl;
                     if (sl == 0) {
                         load_a(fa[cur ^ 1], 1, 0);
@@ -334,7 +344,7 @@ __global__ __launch_bounds__(256, 2) void k_tower(TowerArgs A)
         // bias slot of tower layer L is (L + 1) & 1 (slot 0 held conv1's); odd layers close a block
         if (layer & 1) epilogue(lbias + ((layer + 1) & 1) * 128, yes{}, yes{});
         else epilogue(lbias + ((layer + 1) & 1) * 128, no{}, no{});
-        __syncthreads();
+        barrier_dma();
         if (layer < 28) stamp(4 + 2 * layer);
     }
 
@@ -352,7 +362,7 @@ __global__ __launch_bounds__(256, 2) void k_tower(TowerArgs A)
     for (int nt = 0; nt < 3; nt++)
 #pragma unroll
         for (int i = 0; i < 16; i++) hacc[nt][i] = 0.f;
-    __syncthreads();
+    barrier_dma();
 #pragma unroll
     for (int kk = 0; kk < 8; kk++) {
         const int c = kk * 2 + h;
@@ -499,7 +509,7 @@ __global__ __launch_bounds__(256, 2) void k_tower16(TowerArgs A)
         }
     }
     zero_acc();
-    __syncthreads();
+    barrier_dma();
 #pragma unroll
     for (int pair = 0; pair < 5; pair++) {                           // K-step = taps (2 pair, 2 pair + 1) x 16 planes
         const int tap = 2 * pair + (q >> 1);
@@ -522,21 +532,18 @@ __global__ __launch_bounds__(256, 2) void k_tower16(TowerArgs A)
             for (int mt = 0; mt < 4; mt++)
                 acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mt], bf[nt], acc[mt][nt], 0, 0, 0);
     }
-    __syncthreads();                                                 // every wave is done with planes and tap slices
+    barrier_dma();                                                 // every wave is done with planes and tap slices
     stamp(1);
 
     // weight stream of the 128-channel layers: as in k_tower (stage g -> buffer g & 1)
     const int nlayers = 2 * A.nblocks, nstages = nlayers * 18;
     const rsrc_t wrsrc = make_rsrc(A.wt, nlayers * 9 * COUT * COUT * 2);
-    int wsrc[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const int i = (wave * 4 + j) * 64 + lane, row = i >> 3, cp = i & 7;
-        wsrc[j] = row * 256 + ((cp ^ ((row >> 1) & 7)) * 16);
-    }
+    // piece j of this wave covers rows (wave * 4 + j) * 8 + (lane >> 3) of the stage; its source swizzle
+    // (row >> 1) & 7 = (lane >> 4) ^ ((j & 1) << 2): two per-lane offsets, the rest is scalar
+    const int wsrc_even = (lane >> 3) * 256 + (((lane & 7) ^ (lane >> 4)) << 4), wsrc_odd = wsrc_even ^ 64;
     auto stage_piece = [&](int g, int buf, int j) {
-        const int soff = (g >> 1) * (COUT * COUT * 2) + (g & 1) * 128;
-        dma16_buf_abs(wrsrc, wsrc[j], soff, buf * WBUF_BYTES + (wave * 4 + j) * 1024);
+        const int soff = (g >> 1) * (COUT * COUT * 2) + (g & 1) * 128 + (wave * 4 + j) * 2048;
+        dma16_buf_abs(wrsrc, (j & 1) ? wsrc_odd : wsrc_even, soff, buf * WBUF_BYTES + (wave * 4 + j) * 1024);
     };
     // A fragment (weight tile mt, K-step kk of a stage): abase ^ (kk << 6), + mt * 2048
     const int abase = (hc * 64 + r16) * 128 + ((q ^ ((r16 >> 1) & 7)) << 4);
@@ -557,27 +564,32 @@ __global__ __launch_bounds__(256, 2) void k_tower16(TowerArgs A)
 
     // epilogue: acc + bias [+ residual] -> ReLU -> bf16 -> LDS rows in place (+ keep as next residual)
     auto epilogue = [&](int lb, auto add_res, auto keep_res) {     // lb: LDS offset of this layer's 128 biases
+        // everything the stores need is re-derived from the lane id here, behind an optimisation
+        // barrier: kept live across the main loop these values cost ~20 registers (spilled)
+        int ln;                                                       // lane id, 2 VALU, not CSE-able
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
+        const int r = ln & 15, qq = ln >> 4;
         int sb[6];
 #pragma unroll
         for (int nt = 0; nt < 6; nt++) {
-            const int p = nt * 16 + r16 < PIX ? nt * 16 + r16 : 0;
-            sb[nt] = act_off + p * 256 + (q & 1) * 8 + (((hc * 8 + (q >> 1)) ^ ((p & 7) << 1)) << 4);
-            asm volatile("" : "+v"(sb[nt]));
+            const int p = nt * 16 + r < PIX ? nt * 16 + r : 0;
+            sb[nt] = act_off + p * 256 + (qq & 1) * 8 + (((hc * 8 + (qq >> 1)) ^ ((p & 7) << 1)) << 4);
         }
+        const int lbq = lb + (hc * 64 + 4 * qq) * 4;
 #pragma unroll
         for (int mt = 0; mt < 4; mt++) {
-            const f32x4 b4 = lds_ldf4(lb + (hc * 64 + mt * 16 + 4 * q) * 4);
+            const f32x4 b4 = lds_ldf4(lbq + mt * 64);
 #pragma unroll
             for (int nt = 0; nt < 6; nt++) {
                 float v0 = acc[mt][nt][0] + b4[0], v1 = acc[mt][nt][1] + b4[1];
                 float v2 = acc[mt][nt][2] + b4[2], v3 = acc[mt][nt][3] + b4[3];
                 if constexpr (decltype(add_res)::value) {
-                    const uint2 r = xres[mt][nt];
-                    v0 += bf16_lo(r.x); v1 += bf16_hi(r.x); v2 += bf16_lo(r.y); v3 += bf16_hi(r.y);
+                    const uint2 rr = xres[mt][nt];
+                    v0 += bf16_lo(rr.x); v1 += bf16_hi(rr.x); v2 += bf16_lo(rr.y); v3 += bf16_hi(rr.y);
                 }
                 const uint2 pk = make_uint2(relu_bf16x2(pack_bf16x2(v0, v1)), relu_bf16x2(pack_bf16x2(v2, v3)));
                 if constexpr (decltype(keep_res)::value) xres[mt][nt] = pk;
-                if (nt < 5 || r16 < PIX - 80) lds_st64(sb[nt] ^ (mt << 5), pk);
+                if (nt < 5 || r < PIX - 80) lds_st64(sb[nt] ^ (mt << 5), pk);
             }
         }
     };
@@ -590,7 +602,7 @@ __global__ __launch_bounds__(256, 2) void k_tower16(TowerArgs A)
         if (wave == 1 && lane < 32) dma16_abs(A.bias + 128 + lane * 4, BIAS + 512);
     }
     epilogue(BIAS, no{}, yes{});
-    __syncthreads();
+    barrier_dma();
     stamp(2);
 
     // ---------------------------------------------------------------- residual tower
@@ -614,7 +626,7 @@ __global__ __launch_bounds__(256, 2) void k_tower16(TowerArgs A)
             for (int ks = 0; ks < 4; ks++) {                        // 4 K-steps of 32 channels = 2 weight stages
                 const int sl = ks >> 1, kk = ks & 1, cur = ks & 1;
                 const int g = layer * 18 + tap * 2 + sl;
-                if (kk == 1) __syncthreads();                        // stage st+1 has landed, nobody reads buffer sl any more
+                if (kk == 1) barrier_dma();                        // stage st+1 has landed, nobody reads buffer sl any more
 #pragma unroll
                 for (int n = 0; n < 6; n++) {                        // pixel tile n: 4 MFMAs
                     // activation fragment two tiles ahead (this K-step, or the next one's first two)
@@ -647,7 +659,7 @@ __global__ __launch_bounds__(256, 2) void k_tower16(TowerArgs A)
         if (layer < 28) stamp(3 + 2 * layer);
         if (layer & 1) epilogue(BIAS + ((layer + 1) & 1) * 512, yes{}, yes{});
         else epilogue(BIAS + ((layer + 1) & 1) * 512, no{}, no{});
-        __syncthreads();
+        barrier_dma();
         if (layer < 28) stamp(4 + 2 * layer);
     }
 
@@ -667,7 +679,7 @@ __global__ __launch_bounds__(256, 2) void k_tower16(TowerArgs A)
         for (int nt = 0; nt < 6; nt++)
 #pragma unroll
             for (int i = 0; i < 4; i++) hacc[m][nt][i] = 0.f;
-    __syncthreads();
+    barrier_dma();
     const int nm = hc == 0 ? 2 : 1;                                  // policy: rows 0..31, value: rows 32..47
 #pragma unroll
     for (int ks = 0; ks < 4; ks++) {
@@ -790,7 +802,7 @@ __global__ __launch_bounds__(256, 2) void k_mfma_probe(const uint32_t *seed, con
             if (i >= 8192) w = relu_bf16x2(w);
             reinterpret_cast<uint32_t *>(lds)[i] = w;
         }
-        __syncthreads();
+        barrier_dma();
     }
     bf16x8 a[2], b[3];
     for (int i = 0; i < 8; i++) {
