@@ -437,7 +437,8 @@ __device__ __forceinline__ void dma16_buf_abs(rsrc_t rsrc, int voffset, int soff
 }
 #pragma clang diagnostic pop
 
-template <bool STAMP>
+// ABL (diagnostic builds only, wrong results): 1 = no weight refills, 2 = no stage barriers, 3 = both
+template <bool STAMP, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void k_tower16(TowerArgs A)
 {
     constexpr int ACT0 = 2 * WBUF_BYTES, ZROW = ACT0 + 2 * ACT_BYTES, BIAS = ZROW + 256;   // bias: [2][128] f32
@@ -551,14 +552,11 @@ __global__ __launch_bounds__(256, 2) void k_tower16(TowerArgs A)
         af = lds_ld128((abase ^ (kk << 6)) + sl * WBUF_BYTES + mt * 2048);
     };
     // B fragment (pixel tile nt, K-step ks of the 128 channels): a0[nt] ^ (ks << 6)
-    auto tap_addr = [&](int (&a0)[6], int tap) {
+    auto tap_addr1 = [&](int nt, int tap) {
         const int off = (tap / 3 - 1) * 9 + (tap % 3 - 1);
-#pragma unroll
-        for (int nt = 0; nt < 6; nt++) {
-            const bool ok = (vm[nt / 3] >> ((nt % 3) * 9 + tap)) & 1u;
-            const int sp = nt * 16 + r16 + off;
-            a0[nt] = ok ? act_off + sp * 256 + ((q ^ ((sp & 7) << 1)) << 4) : ZROW + (q << 4);
-        }
+        const bool ok = (vm[nt / 3] >> ((nt % 3) * 9 + tap)) & 1u;
+        const int sp = nt * 16 + r16 + off;
+        return ok ? act_off + sp * 256 + ((q ^ ((sp & 7) << 1)) << 4) : ZROW + (q << 4);
     };
     auto load_b1 = [&](bf16x8 &bf, int a, int ks) { bf = lds_ld128(a ^ (ks << 6)); };
 
@@ -615,31 +613,33 @@ __global__ __launch_bounds__(256, 2) void k_tower16(TowerArgs A)
         zero_acc();
         if (wave == 1 && lane < 32 && layer + 1 < nlayers)          // next layer's bias, slot (layer + 2) & 1
             dma16_abs(A.bias + (size_t)(layer + 2) * 128 + lane * 4, BIAS + (layer & 1) * 512);
-        int a0[6];
-        tap_addr(a0, 0);
+        int a0[6];                                                  // this tap's row addresses, replaced in place
+#pragma unroll                                                      // by the next tap's as soon as each is dead
+        for (int nt = 0; nt < 6; nt++) a0[nt] = tap_addr1(nt, 0);
         load_b1(fb[0], a0[0], 0);
         load_b1(fb[1], a0[1], 0);
         for (int tap = 0; tap < 9; tap++) {
-            int a0n[6];
-            tap_addr(a0n, tap < 8 ? tap + 1 : 8);
+            const int tapn = tap < 8 ? tap + 1 : 8;
 #pragma unroll
             for (int ks = 0; ks < 4; ks++) {                        // 4 K-steps of 32 channels = 2 weight stages
                 const int sl = ks >> 1, kk = ks & 1, cur = ks & 1;
                 const int g = layer * 18 + tap * 2 + sl;
-                if (kk == 1) barrier_dma();                        // stage st+1 has landed, nobody reads buffer sl any more
+                if (kk == 1 && !(ABL & 2)) barrier_dma();          // stage st+1 has landed, nobody reads buffer sl any more
 #pragma unroll
                 for (int n = 0; n < 6; n++) {                        // pixel tile n: 4 MFMAs
                     // activation fragment two tiles ahead (this K-step, or the next one's first two)
                     const int tb = n + 2;
-                    if (tb < 6) load_b1(fb[tb % 3], a0[tb], ks);
-                    else if (ks < 3) load_b1(fb[tb % 3], a0[tb - 6], ks + 1);
-                    else load_b1(fb[tb % 3], a0n[tb - 6], 0);
+                    if (ks == 3 && n == 0) { a0[0] = tap_addr1(0, tapn); a0[1] = tap_addr1(1, tapn); }
+                    if (tb < 6) {
+                        load_b1(fb[tb % 3], a0[tb], ks);
+                        if (ks == 3) a0[tb] = tap_addr1(tb, tapn);
+                    } else load_b1(fb[tb % 3], a0[tb - 6], ks < 3 ? ks + 1 : 0);
                     // next K-step's weight fragments, one per tile; the refill of this buffer two stages ahead
                     if (n < 4) {
                         if (kk == 0) load_a1(fa[cur ^ 1][n], n, sl, 1);
                         else {
                             load_a1(fa[cur ^ 1][n], n, sl ^ 1, 0);
-                            stage_piece(g + 2 < nstages ? g + 2 : nstages - 1, sl, n);
+                            if (!(ABL & 1)) stage_piece(g + 2 < nstages ? g + 2 : nstages - 1, sl, n);
                         }
                     }
 #pragma unroll
@@ -649,12 +649,10 @@ __global__ __launch_bounds__(256, 2) void k_tower16(TowerArgs A)
                     if (n < 4) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
                     else __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    if (kk == 1 && n < 4) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    if (kk == 1 && n < 4 && !(ABL & 1)) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
                     __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
                 }
             }
-#pragma unroll
-            for (int nt = 0; nt < 6; nt++) a0[nt] = a0n[nt];
         }
         if (layer < 28) stamp(3 + 2 * layer);
         if (layer & 1) epilogue(BIAS + ((layer + 1) & 1) * 512, yes{}, yes{});
@@ -729,7 +727,7 @@ __global__ __launch_bounds__(256, 2) void k_tower16(TowerArgs A)
 
 static int g_tower_variant = 1;     // 1 = k_tower16 (v_mfma_f32_16x16x32_bf16), 0 = k_tower (32x32x16)
 // diagnostic switch (not part of the public ABI): both kernels compute the same function
-extern "C" void xq_tower_set_variant(int v) { g_tower_variant = v ? 1 : 0; }
+extern "C" void xq_tower_set_variant(int v) { g_tower_variant = v; }
 
 template <bool STAMP>
 static int launch_tower(void *stream, const void *planes, const void *w1, const void *wt, const void *bias, const void *wh,
@@ -745,12 +743,22 @@ static int launch_tower(void *stream, const void *planes, const void *w1, const 
             hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tower16<STAMP>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 LDS_BYTES) != hipSuccess)
             return XQ_E_HIP;
+        if (STAMP)
+            for (const void *f : { reinterpret_cast<const void *>(&k_tower16<true, 1>), reinterpret_cast<const void *>(&k_tower16<true, 2>),
+                                   reinterpret_cast<const void *>(&k_tower16<true, 3>) })
+                if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) return XQ_E_HIP;
         attr_set = true;
     }
     TowerArgs a{ (const uint16_t *)planes, (const uint16_t *)w1, (const uint16_t *)wt, (const float *)bias,
                  (const uint16_t *)wh, (const float *)bh, (uint16_t *)policy_out, (uint16_t *)value_out, n_boards, n_blocks,
                  (unsigned long long *)stamps };
-    if (g_tower_variant)
+    if (STAMP && g_tower_variant >= 2) {        // ablation builds ride on the stamp entry point
+        const dim3 grid((n_boards + 1) / 2), blk(256);
+        hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+        if (g_tower_variant == 2) hipLaunchKernelGGL((k_tower16<true, 1>), grid, blk, LDS_BYTES, st, a);
+        else if (g_tower_variant == 3) hipLaunchKernelGGL((k_tower16<true, 2>), grid, blk, LDS_BYTES, st, a);
+        else hipLaunchKernelGGL((k_tower16<true, 3>), grid, blk, LDS_BYTES, st, a);
+    } else if (g_tower_variant)
         hipLaunchKernelGGL(k_tower16<STAMP>, dim3((n_boards + 1) / 2), dim3(256), LDS_BYTES, reinterpret_cast<hipStream_t>(stream), a);
     else
         hipLaunchKernelGGL(k_tower<STAMP>, dim3((n_boards + 1) / 2), dim3(256), LDS_BYTES, reinterpret_cast<hipStream_t>(stream), a);

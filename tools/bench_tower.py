@@ -48,6 +48,13 @@ fn = L.xq_tower_debug_stamps
 fn.argtypes = [C.c_void_p] * 9 + [C.c_int, C.c_int, C.c_void_p]
 nwg = (G + 1) // 2
 stamps = torch.zeros(nwg * 64, dtype=torch.int64, device="cuda")
+if variant == 1:
+    # ablation builds of k_tower16 (results are wrong on purpose): what the weight refills / stage barriers cost
+    for v, name in ((1, "stamped build"), (2, "no weight refills"), (3, "no stage barriers"), (4, "neither")):
+        L.xq_tower_set_variant(v)
+        ms = timeit(lambda: fn(*args, stamps.data_ptr()), it=10)
+        print("k_tower16 %s: %.3f ms" % (name, ms))
+    L.xq_tower_set_variant(1)
 for _ in range(2):
     fn(*args, stamps.data_ptr())
 torch.cuda.synchronize()
