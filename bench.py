@@ -59,7 +59,7 @@ def pmc_traffic(kernel, G, S, blocks, fetch_factor=1.0):
     if not (G == 16384 and S == 50 and blocks == 6):
         return None
     k = None
-    for name in ("r01f_pmc_kernels.json", "r01d_pmc_kernels.json"):          # newest pass that has the kernel
+    for name in ("r01g_pmc_kernels.json", "r01f_pmc_kernels.json", "r01d_pmc_kernels.json"):          # newest pass that has the kernel
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
             k = json.load(open(path))["kernels"].get(kernel)
@@ -272,7 +272,7 @@ def main():
         if fused:       # k_tower: conv1 + 2*blocks convs + both heads per launch
             n_conv = len(tower_events)
             conv_fl = 2.0 * rows * 90 * (16 * 9 * 128 + 2 * args.blocks * 128 * 9 * 128 + 128 * 40)
-            kname, kdesc = "k_tower", "hand-written single-launch trunk: conv3x3(16->128) + %d fused residual convs + 1x1 heads, activations resident in LDS" % (2 * args.blocks)
+            kname, kdesc = "k_tower", "k_tower16, hand-written single-launch trunk on v_mfma_f32_16x16x32_bf16: conv3x3(16->128) + %d fused residual convs + 1x1 heads, activations resident in LDS" % (2 * args.blocks)
         else:
             n_conv = 2 * args.blocks * len(tower_events)
             conv_fl = 2.0 * rows * 90 * 128 * 9 * 128
