@@ -1197,3 +1197,46 @@ def test_self_play_api_mirror_vs_reference_golden(L, golden_dir):
         self_play_game(HashNetEvaluator(0), num_simulations=8)
     assert parallel_self_play(HashNetEvaluator(0), 2, num_simulations=8, seeds=[0, 1]) == []     # failed games are dropped
     assert issubclass(InterruptedWithResults, Exception) and InterruptedWithResults([1]).results == [1]
+
+
+def test_bench_contract_line(L, monkeypatch, capsys):
+    """bench.py's one JSON line on a tiny workload, in process: every key of the driver's contract,
+    the two objects this tier adds (`roofline`, `cpu_baseline`), and the same again through the
+    RCCL code path with a single rank (init, all-gather of the sample records, barrier, MAX
+    all-reduce of the time)."""
+    import importlib
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    monkeypatch.syspath_prepend(root)
+    bench = importlib.import_module("bench")
+    base = ["bench.py", "--games", "256", "--sims", "16", "--blocks", "2", "--steps", "1", "--warmup", "0"]
+
+    def run(argv, env=None):
+        monkeypatch.setattr(sys, "argv", argv)
+        for k, v in (env or {}).items():
+            monkeypatch.setenv(k, v)
+        bench.main()
+        lines = [ln for ln in capsys.readouterr().out.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1
+        return json.loads(lines[0])
+
+    d = run(base)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["unit"] == "games/s" and d["n_gpus"] == 1 and d["steps"] == 1 and d["warmup"] == 0
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["dtype"] == "bf16" and d["data"].startswith("synthetic") and "workload" in d["config"]
+    assert abs(d["value"] - 256 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 2500.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["achieved"] > 0 and "traffic" in r
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["unit"] == "games/s" and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+    assert d["games"]["errors"] == 0
+    d2 = run(base + ["--no-cpu-baseline"], env={"XQ_BENCH_FORCE_DIST": "1", "RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1",
+                                                "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29517"})
+    assert d2["n_gpus"] == 1 and "cpu_baseline" not in d2 and d2["value"] > 0
+    import torch.distributed as dist
+    if dist.is_initialized():
+        dist.destroy_process_group()
