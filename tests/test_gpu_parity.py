@@ -537,7 +537,7 @@ def test_single_launch_trunk_equals_per_layer_kernels(L):
     st = torch.cuda.current_stream().cuda_stream
     # both MFMA shapes of the trunk kernel: 1 = v_mfma_f32_16x16x32_bf16 (default), 0 = 32x32x16; only the
     # latter accumulates in the per-layer kernels' order (bit-identical without residual blocks)
-    for variant, blocks, G in ((1, 6, 37), (1, 1, 2), (1, 2, 129), (1, 0, 5), (1, 6, 1), (1, 3, 64),
+    for variant, blocks, G in ((1, 6, 37), (1, 1, 2), (1, 2, 129), (1, 0, 5), (1, 6, 1), (1, 3, 64), (1, 20, 3),
                                (0, 6, 37), (0, 0, 5), (0, 2, 3)):
         L.xq_tower_set_variant(variant)
         torch.manual_seed(10 + blocks)
