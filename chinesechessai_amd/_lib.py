@@ -12,7 +12,8 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libxq_hip.so")
 SOURCES = [os.path.join(CSRC, "xq_engine.hip"), os.path.join(CSRC, "xq_conv.hip"), os.path.join(CSRC, "xq_replay.hip"),
            os.path.join(CSRC, "xq_tower.hip")]
-HEADERS = [os.path.join(CSRC, "xq_device.hpp"), os.path.join(_HERE, "..", "include", "xq_selfplay.h")]
+HEADERS = [os.path.join(CSRC, "xq_device.hpp"), os.path.join(CSRC, "xq_mfma.hpp"),
+           os.path.join(_HERE, "..", "include", "xq_selfplay.h")]
 
 MAX_MOVES = 128
 MAX_PLIES = 70

@@ -8,61 +8,18 @@
 // eval-mode BatchNorm folded into (w, bias).
 //
 // Mapping (implicit GEMM, D = W · Xᵀ so that the accumulator holds 4 consecutive output channels
-// per lane and the epilogue packs them without cross-lane traffic):
-//   workgroup = 4 waves = 4 boards (a board is the halo unit: zero padding never crosses boards)
-//   wave      = one board: 3 pixel tiles (96 >= 90 pixels) x 4 channel tiles (128) of 32x32,
-//               v_mfma_f32_32x32x16_bf16, 12 accumulators = 192 VGPRs, one wave per SIMD
-//   A operand = weights  [32 cout][16 k]   from LDS, tap slice [128 cout][CIN] double-buffered
-//   B operand = activations [16 k][32 pixels] from LDS, the wave's board [90][CIN] (loaded once,
-//               re-read by the 9 taps with a per-lane validity mask for the zero padding)
-//   both LDS images are XOR-swizzled on the 16-byte chunk index (row & 15) so that ds_read_b128 of
-//   32 rows x 256-B stride is conflict-free (cdna_hip_programming.md §6 Guideline 4).
-//   epilogue: +bias -> bf16 -> the wave's own activation region (now dead) -> coalesced 16-B rows,
-//   residual added in fp32 on the way out.
+// per lane and the epilogue packs them without cross-lane traffic): see k_conv3x3_b below (2 boards x
+// 2 output-channel halves per 256-thread workgroup, 2 workgroups per CU).  Since csrc/xq_tower.hip runs
+// the whole trunk in one launch these per-layer kernels are the selectable fallback and the pinned
+// comparison of the trunk kernel.
 #include "../../include/xq_selfplay.h"
-#include <hip/hip_runtime.h>
-#include <stdint.h>
-
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(16))) float f32x16;
-typedef __attribute__((ext_vector_type(4))) float f32x4;
+#include "xq_mfma.hpp"
 
 namespace {
+using namespace xqm;
 
 constexpr int PIX = 90;
 constexpr int COUT = 128;
-
-__device__ __forceinline__ uint32_t pack_bf16x2(float a, float b)
-{
-    // round-to-nearest-even via the hardware conversion (keeps NaN a NaN)
-    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
-    bf16x2 v = { (__bf16)a, (__bf16)b };
-    return *reinterpret_cast<uint32_t *>(&v);
-}
-
-// ReLU on two packed bf16: a negative bf16 has its sign bit set, i.e. is a negative int16, so
-// max(int16, 0) per half zeroes exactly the negative values (-0.0 becomes +0.0, NaN payloads with
-// the sign bit set become 0 — the fp32 path would keep them; activations are finite here).
-__device__ __forceinline__ uint32_t relu_bf16x2(uint32_t w)
-{
-    typedef __attribute__((ext_vector_type(2))) short s16x2;
-    s16x2 v = *reinterpret_cast<s16x2 *>(&w);
-    s16x2 z = { 0, 0 };
-    v = __builtin_elementwise_max(v, z);
-    return *reinterpret_cast<uint32_t *>(&v);
-}
-
-__device__ __forceinline__ float bf16_lo(uint32_t w) { return __uint_as_float(w << 16); }
-__device__ __forceinline__ float bf16_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
-
-// 16-byte global -> LDS copy without a VGPR round trip (LDS-DMA): the LDS destination is
-// wave-uniform base + lane*16, the global source is per lane, so the XOR swizzle goes on the
-// SOURCE address (cdna_hip_programming.md §5.4 rule 21).
-__device__ __forceinline__ void dma16(const void *gsrc, void *lds_wave_base)
-{
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
-                                     (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
-}
 
 // ------------------------------------------------------------------------------------------
 // Variant B: 2 boards per workgroup, 2 workgroups per CU (8 waves, two per SIMD) so that one
@@ -76,28 +33,6 @@ __device__ __forceinline__ void dma16(const void *gsrc, void *lds_wave_base)
 //   variant B: NB 2, KSLP 64  -> 256 threads, 79.6 KB LDS, 2 workgroups per CU, 18 stages
 //   variant C: NB 4, KSLP 128 -> 512 threads, 158.5 KB LDS, 1 workgroup per CU, 9 stages (half the
 //              weight re-streaming and half the barriers / DMA pieces of B)
-// LDS-DMA through a buffer resource: address = SGPR resource + per-lane 32-bit voffset + scalar
-// soffset, i.e. no per-piece 64-bit VALU address arithmetic.
-typedef __amdgpu_buffer_rsrc_t rsrc_t;
-// A workgroup barrier that also publishes LDS-DMA data: each wave first drains ITS OWN pieces
-// (s_waitcnt vmcnt(0)), then the barrier makes every wave's pieces visible.  The wait is explicit:
-// the compiler's fence lowering for __syncthreads() does not promise a vmcnt wait at workgroup scope
-// (it was missing at one of the stage barriers of k_tower16).
-__device__ __forceinline__ void barrier_dma()
-{
-    __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0), expcnt / lgkmcnt untouched
-    __syncthreads();
-}
-
-__device__ __forceinline__ rsrc_t make_rsrc(const void *base, int bytes)
-{
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), /*stride*/ 0, bytes, /*flags*/ 0x00020000);
-}
-__device__ __forceinline__ void dma16_buf(rsrc_t rsrc, int voffset, int soffset, void *lds_wave_base)
-{
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)lds_wave_base, 16, voffset,
-                                             soffset, 0, 0);
-}
 
 template <int CIN, int NB, int KSLP, bool STAMP = false, int ABLATE = 0>
 __global__ __launch_bounds__(NB * 128, 2) void k_conv3x3_b(const uint16_t *__restrict__ x, const uint16_t *__restrict__ w,

@@ -15,63 +15,16 @@
 // [128 cout][64 cin] through a double buffer, 80.1 KB LDS -> 2 workgroups per CU.
 // Reference ops: neural_network.py:54-66,181-187 with eval-mode BatchNorm folded.
 #include "../../include/xq_selfplay.h"
-#include <hip/hip_runtime.h>
-#include <stdint.h>
+#include "xq_mfma.hpp"
 #include <type_traits>
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(16))) float f32x16;
-typedef __attribute__((ext_vector_type(4))) float f32x4;
-typedef __amdgpu_buffer_rsrc_t rsrc_t;
-
 namespace {
+using namespace xqm;
 
 constexpr int PIX = 90, COUT = 128;
 constexpr int ACT_BYTES = PIX * 256;          // one board, 128 channels bf16
 constexpr int WBUF_BYTES = COUT * 128;        // one weight stage: [128 cout][64 cin] bf16
 constexpr int LDS_BYTES = 2 * ACT_BYTES + 2 * WBUF_BYTES + 256 + 2 * 512;
-
-__device__ __forceinline__ uint32_t pack_bf16x2(float a, float b)     // RNE, a in the low half
-{
-    uint32_t r;
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-__device__ __forceinline__ uint32_t relu_bf16x2(uint32_t w)      // max(int16, 0) per half
-{
-    typedef __attribute__((ext_vector_type(2))) short s16x2;
-    s16x2 v = *reinterpret_cast<s16x2 *>(&w);
-    s16x2 z = { 0, 0 };
-    v = __builtin_elementwise_max(v, z);
-    return *reinterpret_cast<uint32_t *>(&v);
-}
-__device__ __forceinline__ float bf16_lo(uint32_t w) { return __uint_as_float(w << 16); }
-__device__ __forceinline__ float bf16_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
-
-__device__ __forceinline__ void dma16(const void *gsrc, void *lds_wave_base)
-{
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
-                                     (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
-}
-// A workgroup barrier that also publishes LDS-DMA data: each wave first drains ITS OWN pieces
-// (s_waitcnt vmcnt(0)), then the barrier makes every wave's pieces visible.  The wait is explicit:
-// the compiler's fence lowering for __syncthreads() does not promise a vmcnt wait at workgroup scope
-// (it was missing at one of the stage barriers of k_tower16).
-__device__ __forceinline__ void barrier_dma()
-{
-    __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0), expcnt / lgkmcnt untouched
-    __syncthreads();
-}
-
-__device__ __forceinline__ rsrc_t make_rsrc(const void *base, int bytes)
-{
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, bytes, 0x00020000);
-}
-__device__ __forceinline__ void dma16_buf(rsrc_t rsrc, int voffset, int soffset, void *lds_wave_base)
-{
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)lds_wave_base, 16, voffset,
-                                             soffset, 0, 0);
-}
 
 struct TowerArgs {
     const uint16_t *planes;    // [G][90][16]
@@ -416,26 +369,6 @@ __global__ __launch_bounds__(256, 2) void k_tower(TowerArgs A)
 //   * the input conv packs two taps (2 x 16 planes) into one K-step and stages all its weights
 //     (36,864 B, over the still unused activation rows) at once: no barriers inside it.
 // ------------------------------------------------------------------------------------------
-// LDS by absolute byte offset (the kernel has no static __shared__, so the dynamic allocation starts
-// at 0): spares the per-access add of the relocatable base that `extern __shared__` arrays cost
-#define XQ_AS3 __attribute__((address_space(3)))
-#pragma clang diagnostic push
-#pragma clang diagnostic ignored "-Wint-to-pointer-cast"
-typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
-typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
-__device__ __forceinline__ bf16x8 lds_ld128(int off) { return *(const XQ_AS3 bf16x8 *)(uint32_t)off; }
-__device__ __forceinline__ f32x4 lds_ldf4(int off) { return *(const XQ_AS3 f32x4 *)(uint32_t)off; }
-__device__ __forceinline__ void lds_st64(int off, uint2 v) { *(XQ_AS3 u32x2 *)(uint32_t)off = u32x2{ v.x, v.y }; }
-__device__ __forceinline__ void lds_st128(int off, uint4 v) { *(XQ_AS3 u32x4 *)(uint32_t)off = u32x4{ v.x, v.y, v.z, v.w }; }
-__device__ __forceinline__ void dma16_abs(const void *gsrc, int lds_off)
-{
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc, (XQ_AS3 void *)(uint32_t)lds_off, 16, 0, 0);
-}
-__device__ __forceinline__ void dma16_buf_abs(rsrc_t rsrc, int voffset, int soffset, int lds_off)
-{
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (XQ_AS3 void *)(uint32_t)lds_off, 16, voffset, soffset, 0, 0);
-}
-#pragma clang diagnostic pop
 
 // ABL (diagnostic builds only, wrong results): 1 = no weight refills, 2 = no stage barriers, 3 = both
 template <bool STAMP, int ABL = 0>
