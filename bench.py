@@ -132,7 +132,7 @@ def cpu_baseline(blocks, sims, workers=4, plies=70, max_cores=16):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--games", type=int, default=16384, help="concurrent games per GPU")
     ap.add_argument("--sims", type=int, default=50)
