@@ -1079,7 +1079,7 @@ def test_virtual_loss_is_opt_in_and_matches_its_restatement(L):
 def test_extensions_with_the_real_network(L):
     """Tree reuse + virtual loss + root noise together on the bf16 network path (8 evaluator rows per
     game): games complete without errors, only legal moves are played (rules oracle replay), pi of
-    every sample sums to 1 and the run is repeatable."""
+    every sample sums to 1."""
     import torch
     from chinesechessai_amd.engine import SelfPlayEngine, TorchNetEvaluator
     from chinesechessai_amd.neural_network import ChessNet
@@ -1102,8 +1102,7 @@ def test_extensions_with_the_real_network(L):
         assert (vl == 0).all() and nodes.max() < 65472
         return bt
 
-    a, b = run(), run()
-    assert np.array_equal(a.chosen, b.chosen) and np.array_equal(a.s_counts, b.s_counts)
+    a = run()          # (no repeatability assertion here: library GEMMs need not be run-to-run identical)
     assert int(a.error.sum()) == 0 and (a.n_plies == 30).all()
     for g in range(NG):
         env = xo.OracleEnv()
