@@ -139,7 +139,8 @@ __global__ __launch_bounds__(256, 2) void k_tower(TowerArgs A)
         for (int nt = 0; nt < 3; nt++) {
             const bool ok = (vmask[nt] >> tap) & 1u;
             const int sp = opix[nt] + off;
-            const int a = ok ? act_off + sp * 32 + ((((sp >> 3) & 1) ^ h) << 4) : ZROW + (h << 4);
+            // (padding lanes read the zero region at the slot their own row would have used: no bank conflicts)
+            const int a = (ok ? act_off + sp * 32 : ZROW + (sp & 7) * 32) + ((((sp >> 3) & 1) ^ h) << 4);
             bf[nt] = *reinterpret_cast<const bf16x8 *>(lds + a);
         }
 #pragma unroll
@@ -186,7 +187,7 @@ __global__ __launch_bounds__(256, 2) void k_tower(TowerArgs A)
         for (int nt = 0; nt < 3; nt++) {
             const bool ok = (vmask[nt] >> tap) & 1u;
             const int sp = opix[nt] + off;
-            a0[nt] = ok ? act_off + sp * 256 + (((sp & 15) ^ h) << 4) : ZROW + (h << 4);
+            a0[nt] = (ok ? act_off + sp * 256 : ZROW) + (((sp & 15) ^ h) << 4);
         }
     };
 
@@ -455,7 +456,7 @@ __global__ __launch_bounds__(256, 2) void k_tower16(TowerArgs A)
         for (int nt = 0; nt < 6; nt++) {
             const bool ok = tap_real && ((vm[nt / 3] >> ((nt % 3) * 9 + tp)) & 1u);
             const int sp = nt * 16 + r16 + off;
-            bf[nt] = lds_ld128(ok ? pl_off + sp * 32 + (q & 1) * 16 : ZROW + (q & 1) * 16);
+            bf[nt] = lds_ld128((ok ? pl_off + sp * 32 : ZROW + (sp & 7) * 32) + (q & 1) * 16);
         }
 #pragma unroll
         for (int mt = 0; mt < 4; mt++)
@@ -489,7 +490,9 @@ __global__ __launch_bounds__(256, 2) void k_tower16(TowerArgs A)
         const int off = (tap / 3 - 1) * 9 + (tap % 3 - 1);
         const bool ok = (vm[nt / 3] >> ((nt % 3) * 9 + tap)) & 1u;
         const int sp = nt * 16 + r16 + off;
-        return ok ? act_off + sp * 256 + ((q ^ ((sp & 7) << 1)) << 4) : ZROW + (q << 4);
+        // padding lanes read the 256-B zero row at the 16-B slot their own row would have used, so a
+        // ds_read_b128 lane group stays conflict-free whatever the mix of real and padding pixels
+        return (ok ? act_off + sp * 256 : ZROW) + ((q ^ ((sp & 7) << 1)) << 4);
     };
     auto load_b1 = [&](bf16x8 &bf, int a, int ks) { bf = lds_ld128(a ^ (ks << 6)); };
 
