@@ -11,9 +11,13 @@
 // prologue / epilogue phases (tools/bench_conv.py stamps); here only the weight stream is left.
 //
 // Same tiling as k_conv3x3_b variant B: workgroup = 4 waves = 2 boards x 2 output-channel halves,
-// wave tile 96 pixels x 64 channels (6 accumulators), weights streamed by LDS-DMA in K-slices
-// [128 cout][64 cin] through a double buffer, 80.1 KB LDS -> 2 workgroups per CU.
-// Reference ops: neural_network.py:54-66,181-187 with eval-mode BatchNorm folded.
+// wave tile 96 pixels x 64 channels, weights streamed by LDS-DMA in K-slices [128 cout][64 cin]
+// through a double buffer, 80.1 KB LDS -> 2 workgroups per CU.  Two builds of that dataflow:
+//   k_tower16 (default)  v_mfma_f32_16x16x32_bf16, hand-pipelined stage loop — the chip holds a higher
+//                        clock on this MFMA shape under its power cap (3.5 vs 3.9 ms per 16,384 boards)
+//   k_tower              v_mfma_f32_32x32x16_bf16, the first version; xq_tower_set_variant(0) selects it
+// plus diagnostic entry points (phase stamps, ablation builds, bare-MFMA power probes) used by
+// tools/bench_tower.py.  Reference ops: neural_network.py:54-66,181-187 with eval-mode BatchNorm folded.
 #include "../../include/xq_selfplay.h"
 #include "xq_mfma.hpp"
 #include <type_traits>
