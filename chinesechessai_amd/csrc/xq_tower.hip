@@ -375,7 +375,8 @@ __global__ __launch_bounds__(256, 2) void k_tower(TowerArgs A)
 //     (36,864 B, over the still unused activation rows) at once: no barriers inside it.
 // ------------------------------------------------------------------------------------------
 
-// ABL (diagnostic builds only, wrong results): 1 = no weight refills, 2 = no stage barriers, 3 = both
+// ABL (diagnostic builds only, wrong results): 1 = no weight refills, 2 = no stage barriers, 3 = both,
+// 4 = every tap reads the centre tap's rows (no per-tap address arithmetic)
 template <bool STAMP, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void k_tower16(TowerArgs A)
 {
@@ -491,6 +492,7 @@ __global__ __launch_bounds__(256, 2) void k_tower16(TowerArgs A)
     };
     // B fragment (pixel tile nt, K-step ks of the 128 channels): a0[nt] ^ (ks << 6)
     auto tap_addr1 = [&](int nt, int tap) {
+        if (ABL & 4) tap = 4;                                         // ablation: no per-tap address arithmetic
         const int off = (tap / 3 - 1) * 9 + (tap % 3 - 1);
         const bool ok = (vm[nt / 3] >> ((nt % 3) * 9 + tap)) & 1u;
         const int sp = nt * 16 + r16 + off;
@@ -685,7 +687,7 @@ static int launch_tower(void *stream, const void *planes, const void *w1, const 
             return XQ_E_HIP;
         if (STAMP)
             for (const void *f : { reinterpret_cast<const void *>(&k_tower16<true, 1>), reinterpret_cast<const void *>(&k_tower16<true, 2>),
-                                   reinterpret_cast<const void *>(&k_tower16<true, 3>) })
+                                   reinterpret_cast<const void *>(&k_tower16<true, 3>), reinterpret_cast<const void *>(&k_tower16<true, 4>) })
                 if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) return XQ_E_HIP;
         attr_set = true;
     }
@@ -695,7 +697,8 @@ static int launch_tower(void *stream, const void *planes, const void *w1, const 
     if (STAMP && g_tower_variant >= 2) {        // ablation builds ride on the stamp entry point
         const dim3 grid((n_boards + 1) / 2), blk(256);
         hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-        if (g_tower_variant == 2) hipLaunchKernelGGL((k_tower16<true, 1>), grid, blk, LDS_BYTES, st, a);
+        if (g_tower_variant == 5) hipLaunchKernelGGL((k_tower16<true, 4>), grid, blk, LDS_BYTES, st, a);
+        else if (g_tower_variant == 2) hipLaunchKernelGGL((k_tower16<true, 1>), grid, blk, LDS_BYTES, st, a);
         else if (g_tower_variant == 3) hipLaunchKernelGGL((k_tower16<true, 2>), grid, blk, LDS_BYTES, st, a);
         else hipLaunchKernelGGL((k_tower16<true, 3>), grid, blk, LDS_BYTES, st, a);
     } else if (g_tower_variant)

@@ -50,7 +50,8 @@ nwg = (G + 1) // 2
 stamps = torch.zeros(nwg * 64, dtype=torch.int64, device="cuda")
 if variant == 1:
     # ablation builds of k_tower16 (results are wrong on purpose): what the weight refills / stage barriers cost
-    for v, name in ((1, "stamped build"), (2, "no weight refills"), (3, "no stage barriers"), (4, "neither")):
+    for v, name in ((1, "stamped build"), (2, "no weight refills"), (3, "no stage barriers"), (4, "neither"),
+                    (5, "no per-tap address arithmetic")):
         L.xq_tower_set_variant(v)
         ms = timeit(lambda: fn(*args, stamps.data_ptr()), it=10)
         print("k_tower16 %s: %.3f ms" % (name, ms))
