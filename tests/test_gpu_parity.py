@@ -1233,8 +1233,12 @@ def test_bench_contract_line(L, monkeypatch, capsys):
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "games/s" and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
     assert d["games"]["errors"] == 0
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     d2 = run(base + ["--no-cpu-baseline"], env={"XQ_BENCH_FORCE_DIST": "1", "RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1",
-                                                "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29517"})
+                                                "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
     assert d2["n_gpus"] == 1 and "cpu_baseline" not in d2 and d2["value"] > 0
     import torch.distributed as dist
     if dist.is_initialized():
