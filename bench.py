@@ -2,7 +2,13 @@
 """bench.py — self-play games/sec at fixed MCTS sims (BASELINE.json metric) on N MI355X.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: launched by torch.distributed.run, one rank per GPU, RCCL)
+
+N > 1 needs one rank per GPU (RCCL).  Either the caller starts the ranks (`python -m
+torch.distributed.run --nproc-per-node N ... bench.py --gpus N`: WORLD_SIZE is set, bench.py is a
+rank) or nobody did (bare `python bench.py --gpus N`): then bench.py starts them itself as a CHILD
+process (torch.distributed.run; never exec) before anything touches the GPU, relays rank 0's JSON
+line and exits with the child's code — the counterpart of the reference's pool start
+(self_play.py:404-408).  A rank whose WORLD_SIZE differs from --gpus refuses to run.
 
 A "step" = one pass of the hot path over one batch: G concurrent games per GPU played from the
 start position to the end (rules -> MCTS -> network leaf evaluation -> (state, pi, z) samples),
@@ -13,11 +19,11 @@ positions, per-game seeds base+g.  Games shard across GPUs with no data-path col
 (weak scaling: G per GPU fixed).
 
 Prints ONE JSON line (rank 0).  `roofline` = the dominant kernel of the step, the hand-written
-fused conv k_conv3x3_b<128> (MFMA-bound, ~83 % of GPU time); `roofline_net` = the whole network
-forward; `roofline_tree` = the tree/rules kernel k_search_round (HBM-bound integer work); all
-measured live with events on the stream the kernels run on.
+single-launch trunk k_tower16 (csrc/xq_tower.hip; MFMA-bound, ~85 % of GPU time); `roofline_net` =
+the whole network forward; `roofline_tree` = the tree/rules kernel k_search_round (HBM-bound
+integer work); all measured live with events on the stream the kernels run on.
 `cpu_baseline` = the CPU oracle ("port" of the reference algorithm, net on CPU torch) timed on the
-host cores on a bounded sample.
+host cores on a bounded sample (rank 0, N = 1 only).
 """
 import argparse
 import json
@@ -75,7 +81,7 @@ def pmc_traffic(kernel, G, S, blocks, fetch_factor=1.0):
 # CPU baseline: the oracle (C restatement of the reference algorithm) with the net on CPU torch
 # ------------------------------------------------------------------------------------------
 def _cpu_worker(args):
-    idx, blocks, sims, threads, plies, barrier = args
+    idx, blocks, sims, threads, plies, games, reps, barrier = args
     import torch
     torch.set_num_threads(threads)
     from chinesechessai_amd.neural_network import ChessNet
@@ -100,17 +106,28 @@ def _cpu_worker(args):
     cb = xo.EVAL_FN(fn)
     ev = xo.Evaluator(cb, None)
     xo.lib()
-    barrier.wait()
-    t0 = time.time()
-    rc, g = xo.self_play_game(1000 + idx, sims, eval_red=ev, max_moves=plies)
-    return time.time() - t0, g.n_plies, rc
+    xo.self_play_game(999, sims, eval_red=ev, max_moves=1)          # first touch (untimed)
+    out = []
+    for rep in range(reps):
+        barrier.wait()                                               # pool start-up is outside every timed span
+        t0 = time.time()
+        n_plies = 0
+        for k in range(games):
+            rc, g = xo.self_play_game(1000 + (rep * 64 + idx) * 64 + k, sims, eval_red=ev, max_moves=plies)
+            if rc == 0:
+                n_plies += g.n_plies
+        out.append((time.time() - t0, n_plies))
+    return out
 
 
-def cpu_baseline(blocks, sims, workers=4, plies=70, max_cores=16):
-    """4 worker processes x 1 game each, mirroring NUM_WORKERS=4 (config.py:48, self_play.py:404),
-    intra-op threads pinned to cores/4 (the reference's unpinned default oversubscribes,
-    BASELINE.md §2).  Bounded sample: the first `plies` plies of each game, scaled to games/s by
-    plies/70 (random-init games run to the 70-ply cap)."""
+def cpu_baseline(blocks, sims, workers=4, plies=18, games=8, reps=3, max_cores=16):
+    """The structural twin of the reference's 4-process path (NUM_WORKERS = 4, config.py:48;
+    self_play.py:404-408): 4 worker processes, each playing `games` games one after the other with a
+    private net replica on CPU torch, intra-op threads pinned to cores/4 (the reference's unpinned
+    default oversubscribes).  Timing rule of SURVEY.md §8(d): >= 8 games per worker,
+    pool start-up and first touch excluded, median of 3 repetitions.  Bounded sample: the first
+    `plies` plies of every game, scaled to games/s by plies/70 (random-init games run to the 70-ply
+    cap at a near-constant cost per ply); --cpu-baseline-full plays whole games (~100 s)."""
     import multiprocessing as mp
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 4)
     cores = min(cores, max_cores)                 # the box's CPU share for one GPU
@@ -119,13 +136,18 @@ def cpu_baseline(blocks, sims, workers=4, plies=70, max_cores=16):
     mgr = ctx.Manager()
     barrier = mgr.Barrier(workers)
     with ctx.Pool(workers) as pool:
-        res = pool.map(_cpu_worker, [(i, blocks, sims, threads, plies, barrier) for i in range(workers)])
-    wall = max(r[0] for r in res)
-    games_equiv = sum(r[1] for r in res if r[2] == 0) / 70.0
-    return {"value": games_equiv / wall, "unit": "games/s", "cores": workers * threads, "kind": "port",
-            "sample": "%d worker processes x the first %d plies of 1 game each (oracle C rules+MCTS, %d sims, "
-                      "%d-block net fp32 on CPU torch, %d threads each, duplicate leaf rows evaluated as the "
-                      "reference does), scaled by plies/70; wall %.1f s" % (workers, plies, sims, blocks, threads, wall)}
+        res = pool.map(_cpu_worker, [(i, blocks, sims, threads, plies, games, reps, barrier) for i in range(workers)])
+    rates, walls = [], []
+    for rep in range(reps):
+        wall = max(r[rep][0] for r in res)
+        rates.append(sum(r[rep][1] for r in res) / 70.0 / wall)
+        walls.append(wall)
+    return {"value": float(np.median(rates)), "unit": "games/s", "cores": workers * threads, "kind": "port",
+            "sample": "%d worker processes x %d games each, the first %d plies of every game (oracle C rules+MCTS, %d sims, "
+                      "%d-block net fp32 on CPU torch, %d threads each, duplicate leaf rows evaluated as the reference "
+                      "does), scaled by plies/70; median of %d repetitions (%s games/s; walls %s s), pool start-up and "
+                      "first touch excluded" % (workers, games, plies, sims, blocks, threads, reps,
+                                                ", ".join("%.3f" % v for v in rates), ", ".join("%.1f" % v for v in walls))}
 
 
 # ------------------------------------------------------------------------------------------
@@ -139,6 +161,10 @@ def main():
     ap.add_argument("--blocks", type=int, default=6)
     ap.add_argument("--warmup-plies", type=int, default=0, help="0 = full warmup steps; >0 shortens a warmup step to this many plies")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-full", action="store_true", help="cpu_baseline on whole 70-ply games (8 per worker, median of 3: ~100 s)")
+    ap.add_argument("--refill", type=int, default=0, metavar="TOTAL",
+                    help="steady-state mode (reported beside the headline, never instead of it): every step plays TOTAL games "
+                         "per GPU through the --games concurrent slots, a finished game's slot being refilled with the next seed")
     ap.add_argument("--profile-plies", type=int, default=0,
                     help="profiling aid only: stop every step after this many plies (the JSON line is then NOT a benchmark)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
@@ -154,6 +180,90 @@ def main():
     ap.add_argument("--fused-tower", type=int, default=1, help="1 = whole trunk in one launch (k_tower), 0 = one launch per convolution")
     ap.add_argument("--conv-variant", type=int, default=0, help="diagnostic: 1 = 2 boards/WG, 2 = 4 boards/WG (0 = library default)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus))              # before anything initialises the GPU
+    run_rank(args)
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` with no launcher around it: start the N ranks as a child
+    torch.distributed.run (one process per GPU, rendezvous on 127.0.0.1), pass its output through
+    and return its exit code.  The child is a subprocess, never an exec; this process has not
+    touched the GPU and never will."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def run_rank_rehearsal(args, backend, rank, world):
+    """See run_rank: N-rank control flow on CPU (gloo) with a test-provided stand-in engine."""
+    import importlib
+    import torch
+    import torch.distributed as dist
+    from chinesechessai_amd import distributed as xd
+    standin = os.environ.get("XQ_BENCH_STANDIN")
+    if not standin:
+        sys.exit("bench.py: XQ_BENCH_BACKEND=%s needs XQ_BENCH_STANDIN=<module with make_step()> (tests only); "
+                 "the HIP engine has no CPU fallback" % backend)
+    dist.init_process_group(backend)
+    assert dist.get_world_size() == args.gpus == world and dist.get_rank() == rank
+    G, S = args.games, args.sims
+    play = importlib.import_module(standin).make_step(G, S)       # seeds -> uint8 CPU tensor [G * 70 * RECORD_BYTES]
+    gathered = [None]
+
+    def step(base_seed):
+        local = play(xd.game_seeds(base_seed, G * world, rank, world))
+        gathered[0] = xd.all_gather_records(local)
+
+    for w in range(args.warmup):
+        step(7_000_000 + w * G * world)
+    dist.barrier()
+    t0 = time.time()
+    for k in range(args.steps):
+        step(k * G * world)
+    dist.barrier()
+    t = torch.tensor([time.time() - t0], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    if rank == 0:
+        rec = xd.records_to_numpy(gathered[0]).reshape(world, G, 70)
+        print(json.dumps({
+            "metric": "self-play games/sec @ %d MCTS sims" % S, "value": G * world * args.steps / dt, "unit": "games/s",
+            "n_gpus": dist.get_world_size(), "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "n/a",
+            "data": "REHEARSAL of the N-rank control flow on CPU (%s, stand-in engine %s) - not a benchmark" % (backend, standin),
+            "config": {"workload": "%d games per rank, %d sims" % (G, S), "games_per_gpu": G, "sims": S,
+                       "parallelism": "games sharded x%d, all-gather of samples at step end" % world},
+            "gathered_records": int(rec["valid"].sum()), "gathered_games": int((rec["valid"].sum(axis=2) > 0).sum())}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def run_rank(args):
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d: start %d ranks (torch.distributed.run --nproc-per-node %d) or "
+                 "run `python bench.py --gpus %d` bare and let it start them" % (args.gpus, world, args.gpus, args.gpus, args.gpus))
+    backend = os.environ.get("XQ_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        # CPU rehearsal of the N-rank control flow (tests/test_bench_launcher_cpu.py): the launcher, the
+        # rank/world checks, sharded seeds, the production all-gather, barrier + max-over-ranks timing
+        # and the JSON line are the real ones; the HIP engine is replaced by the stand-in module the
+        # test names.  Never a benchmark: the line says so.
+        return run_rank_rehearsal(args, backend, rank, world)
 
     import torch
     import torch.distributed as dist
@@ -166,9 +276,6 @@ def main():
         _lib.lib().xq_conv3x3_set_variant(args.conv_variant)
     if args.search_occ:
         _lib.lib().xq_engine_set_search_occupancy(args.search_occ)
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # XQ_BENCH_FORCE_DIST=1 rehearses the RCCL code path (init, all-gather, barrier, all-reduce)
     # with a single rank under torch.distributed.run
     use_dist = world > 1 or (os.environ.get("XQ_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ)
@@ -176,6 +283,7 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
     else:
         torch.cuda.set_device(0)
     dev = torch.cuda.current_device()
@@ -280,7 +388,7 @@ def main():
         conv_tflops = conv_fl * n_conv / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
         out = {
             "metric": "self-play games/sec @ 50 MCTS sims" if S == 50 else "self-play games/sec @ %d MCTS sims" % S,
-            "value": games / dt, "unit": "games/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": games / dt, "unit": "games/s", "n_gpus": dist.get_world_size() if use_dist else 1, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic" if not args.profile_plies else
             "synthetic; PROFILING RUN truncated to %d plies per step - not a benchmark" % args.profile_plies,
@@ -318,7 +426,7 @@ def main():
                       "draws_by_cap": int((outcomes["reason"] == 8).sum()), "errors": int(outcomes["error"].sum())},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.blocks, S)
+            out["cpu_baseline"] = cpu_baseline(args.blocks, S, plies=70 if args.cpu_baseline_full else 18)
         print(json.dumps(out))
     eng.close()
     if use_dist:

@@ -78,6 +78,10 @@ def play_sharded(make_evaluator, num_games, sims, base_seed=0, temperature=1.0, 
     import torch.distributed as dist
     from .engine import SelfPlayEngine
     rank, world = dist.get_rank(group), dist.get_world_size(group)
+    if num_games < world:
+        # every rank sees the same arguments, so every rank raises: nobody is left waiting in the all-gather
+        raise ValueError("play_sharded: %d games cannot be sharded over %d ranks (each rank needs at least one)"
+                         % (num_games, world))
     lo, hi = shard_range(num_games, rank, world)
     n_local = hi - lo
     n_pad = shard_range(num_games, 0, world)[1]               # largest shard
