@@ -172,9 +172,10 @@ def main():
     ap.add_argument("--root-noise", default="", help="extension (BASELINE C5): 'alpha,eps' Dirichlet root noise, e.g. 0.3,0.25")
     ap.add_argument("--temp-cutoff", type=int, default=0, help="extension (C5): temperature 1.0 before this ply, ~0 after")
     ap.add_argument("--search-occ", type=int, default=0, help="diagnostic: k_search_round waves/SIMD variant (3, 5, 6, 8)")
-    ap.add_argument("--policy-columns", default="all", choices=["all", "reachable"],
-                    help="'reachable' (opt-in): policy FC restricted to the 2.6k of 8,100 columns that can ever be a legal "
-                         "move (result-identical; the default keeps the reference's full head)")
+    ap.add_argument("--policy-columns", default="reachable", choices=["all", "reachable"],
+                    help="'reachable' (default): the policy FC computes the 2,294 of 8,100 columns a legal move can index - the "
+                         "search gathers legal-move logits only (neural_network.py:148-169), the rest are dead outputs; "
+                         "'all': the reference's full 8,100-column head")
     ap.add_argument("--tree-reuse", action="store_true", help="extension: keep the played move's subtree (no reference oracle)")
     ap.add_argument("--virtual-loss", action="store_true", help="extension: up to 8 distinct leaves per game and round (8x the network rows)")
     ap.add_argument("--fused-tower", type=int, default=1, help="1 = whole trunk in one launch (k_tower), 0 = one launch per convolution")
@@ -369,8 +370,7 @@ def run_rank(args):
         games = G * world * args.steps
         rows = eng.n_rows                                   # network rows per forward (one per game; x8 slots with virtual loss)
         fl = net_flops_per_row(args.blocks)
-        if args.policy_columns == "reachable":                 # only the computed FC rows count
-            fl -= 2 * 2880 * (8100 - ev.inet.n_policy)
+        fl -= 2 * 2880 * (8100 - ev.inet.n_policy_real)        # only the policy columns actually computed count (no padding)
         net_tflops = (fl * rows * n_fw) / (fw_ms * 1e-3) / 1e12 if fw_ms > 0 else 0.0
         bpd = tree_bytes_per_descent()
         tree_gbs = (bpd * G * prof["search_launches"]) / (prof["search_ms"] * 1e-3) / 1e9 if prof["search_ms"] > 0 else 0.0
@@ -396,8 +396,9 @@ def run_rank(args):
                                    "random-init weights, start positions, seeds base+g%s" % (
                                        "BASELINE configs[2]: " if (G, S, args.blocks) == (16384, 50, 6) else "",
                                        G, S, args.blocks, args.dtype,
-                                       (", policy FC restricted to the %d reachable-move columns" % ev.inet.n_policy
-                                        if args.policy_columns == "reachable" else "") +
+                                       (", policy FC on the %d columns a legal move can index (of 8,100; the others are never "
+                                        "read by the search and are not counted as work)" % ev.inet.n_policy_real
+                                        if args.policy_columns == "reachable" else ", full 8,100-column policy FC") +
                                        (", Dirichlet root noise %s, temperature 1 -> 0 at ply %d (extensions, no reference oracle)"
                                         % (args.root_noise, args.temp_cutoff)) if (args.root_noise or args.temp_cutoff) else "") +
                                        (", tree reuse (extension)" if args.tree_reuse else "") +

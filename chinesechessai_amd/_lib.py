@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libxq_hip.so")
 SOURCES = [os.path.join(CSRC, "xq_engine.hip"), os.path.join(CSRC, "xq_conv.hip"), os.path.join(CSRC, "xq_replay.hip"),
-           os.path.join(CSRC, "xq_tower.hip")]
+           os.path.join(CSRC, "xq_tower.hip"), os.path.join(CSRC, "xq_policy.hip")]
 HEADERS = [os.path.join(CSRC, "xq_device.hpp"), os.path.join(CSRC, "xq_mfma.hpp"),
            os.path.join(_HERE, "..", "include", "xq_selfplay.h")]
 
@@ -51,8 +51,23 @@ def build(force=False, verbose=False):
     if not force and os.path.exists(LIB_PATH) and all(
             os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
         return LIB_PATH
-    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared",
-           "-std=c++17", "-Wall", "-Wno-unused-function", "-o", LIB_PATH] + SOURCES
+    # one hipcc per source, concurrently (the trunk kernel alone takes ~2 min), then one link
+    flags = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
+    objdir = os.path.join(CSRC, "build")
+    os.makedirs(objdir, exist_ok=True)
+    jobs = []
+    for src in SOURCES:
+        obj = os.path.join(objdir, os.path.basename(src) + ".o")
+        if force or not os.path.exists(obj) or any(os.path.getmtime(obj) < os.path.getmtime(d) for d in [src] + HEADERS):
+            cmd = [hipcc_path()] + flags + ["-c", "-o", obj, src]
+            if verbose:
+                print(" ".join(cmd))
+            jobs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, pr in jobs:
+        if pr.wait() != 0:
+            raise subprocess.CalledProcessError(pr.returncode, cmd)
+    cmd = [hipcc_path(), "--offload-arch=gfx950", "-fPIC", "-shared", "-o", LIB_PATH] + [
+        os.path.join(objdir, os.path.basename(src) + ".o") for src in SOURCES]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
@@ -128,6 +143,8 @@ _SIGNATURES = {
                                        C.c_int, C.c_int, C.c_int]),
     "xq_heads_nhwc_bf16": (C.c_int, [C.c_void_p] * 6 + [C.c_int]),
     "xq_tower_nhwc_bf16": (C.c_int, [C.c_void_p] * 9 + [C.c_int, C.c_int]),
+    "xq_policy_fc_bf16": (C.c_int, [C.c_void_p] * 5 + [C.c_int, C.c_int, C.c_int]),
+    "xq_value_head_bf16": (C.c_int, [C.c_void_p] * 7 + [C.c_int]),
     "xq_replay_last_error": (C.c_char_p, []),
     "xq_replay_create": (C.c_int, [C.c_int, C.c_int64, C.POINTER(C.c_void_p)]),
     "xq_replay_destroy": (None, [C.c_void_p]),

@@ -1353,7 +1353,7 @@ extern "C" int xq_engine_set_logit_columns(xq_engine *e, const int16_t *map, int
 {
     if (!e) return fail(XQ_E_INVALID, "null engine");
     if (!map || n_columns <= 0) { e->E.col_map = nullptr; e->E.n_cols = 0; return 0; }
-    if (n_columns > XQ_POLICY_SIZE) return fail(XQ_E_INVALID, "n_columns > 8100");
+    if (n_columns > 16384) return fail(XQ_E_INVALID, "n_columns > 16384");     // (rows may be padded past 8,100 columns)
     for (int i = 0; i < XQ_POLICY_SIZE; i++)
         if (map[i] < -1 || map[i] >= n_columns) return fail(XQ_E_INVALID, "column map entry out of range");
     HIPCHK(hipSetDevice(e->cfg.device));

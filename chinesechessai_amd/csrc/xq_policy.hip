@@ -1,0 +1,241 @@
+// xq_policy.hip — the policy head's fully-connected layer (neural_network.py:39,64: Linear 2880 -> 8100)
+// as a hand-written bf16 MFMA GEMM for gfx950, replacing the library (hipBLASLt stream-K) kernel:
+//
+//   logits[m][n] = bias[n] + sum_k act[m][k] * w[n][k]      act [M][K] bf16, w [N][K] bf16 (both K-contiguous),
+//                                                          bias f32, logits [M][N] bf16, fp32 accumulation
+//
+// Why hand-written: (1) a fixed accumulation order — the library's stream-K split made self-play with the
+// real network differ from run to run; every output element here is one fp32 chain
+// over k = 0 .. K-1 in 32-wide MFMA steps, identical for every launch, tile position and batch size;
+// (2) the caller restricts N to the columns a legal move can index (2,294 of 8,100, padded to 2,304:
+// neural_network.reachable_policy_columns) — the search only ever gathers legal moves
+// (neural_network.py:148-169), so the other 5,806 logits are dead outputs.
+//
+// Tiling: workgroup = 8 waves = 256 (M) x 192 (N) outputs, K-stage 64; wave (wm, wn) owns 64 x 96 = 4 x 6
+// MFMA tiles (96 accumulator registers: the trunk kernel's wave tile, same 10 fragment reads per 24 MFMAs).
+// 2,304 = 12 x 192 and 16,384 = 64 x 256: 768 workgroups = exactly 3 per CU.  Both operands are streamed by
+// LDS-DMA into a double buffer of [256 + 192 rows][128 B] with the trunk kernel's XOR chunk swizzle (applied
+// on the source address), 7 pieces of 1 KB per wave and stage; stage barriers are raw s_barrier + vmcnt(0)
+// behind the first tile of a stage's second K-step, fragments are double-buffered by K-step (as in
+// k_tower16b).  The MFMA's A operand is the WEIGHT tile, so a lane ends up with 4 consecutive columns of one
+// row: 8-byte stores.  blockIdx -> tile is XCD-aware: the 12 column tiles of a row block run on one XCD,
+// so the activations are fetched into that L2 once.
+#include "../../include/xq_selfplay.h"
+#include "xq_mfma.hpp"
+#include <type_traits>
+
+namespace {
+using namespace xqm;
+
+constexpr int BM = 256, BN = 192;
+constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128, STAGE_BYTES = A_BYTES + W_BYTES;     // 57,344
+constexpr int FC_LDS_BYTES = 2 * STAGE_BYTES;                                              // 114,688
+
+struct FcArgs {
+    const uint16_t *act;      // [M][K]
+    const uint16_t *w;        // [N][K]
+    const float *bias;        // [N]
+    uint16_t *out;            // [M][N]
+    int M, N, K, ncol;
+};
+
+__global__ __launch_bounds__(512, 2) void k_policy_fc(FcArgs P)
+{
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r16 = lane & 15, q = lane >> 4;
+
+    // XCD-aware, bijective blockIdx -> tile (cdna_hip_programming.md T1): blocks b, b + 8, ... share an XCD
+    const int nwg = gridDim.x, orig = blockIdx.x, xcd = orig & 7, qd = nwg >> 3, rem = nwg & 7;
+    const int t = (xcd < rem ? xcd * (qd + 1) : rem * (qd + 1) + (xcd - rem) * qd) + (orig >> 3);
+    const int rb = t / P.ncol, cb = t - rb * P.ncol;
+    const int m0 = rb * BM, n0 = cb * BN;
+    const int K2 = P.K * 2, nst = P.K >> 6;
+    const int rows = P.M - m0 < BM ? P.M - m0 : BM;                   // rows past M read as zeros (buffer bounds)
+    const rsrc_t ra = make_rsrc(P.act + (size_t)m0 * P.K, rows * K2);
+    const rsrc_t rw = make_rsrc(P.w + (size_t)n0 * P.K, BN * K2);
+
+    // piece p (8 rows x 128 B) of an operand tile: rows p * 8 + (lane >> 3); its source chunk is swizzled by
+    // (row >> 1) & 7 = (lane >> 4) + 4 * (p & 1); pieces are dealt p = j * 8 + wave, so p & 1 = wave & 1
+    const int voff = (lane >> 3) * K2 + ((((lane & 7) ^ (lane >> 4)) << 4) ^ ((wave & 1) << 6));
+    auto stage_piece = [&](int s, int buf, int j) {                   // j 0..3: activations, 4..6: weights
+        if (j < 4) {
+            const int p = j * 8 + wave;
+            dma16_buf_abs(ra, voff, p * 8 * K2 + s * 128, buf * STAGE_BYTES + p * 1024);
+        } else {
+            const int p = (j - 4) * 8 + wave;
+            dma16_buf_abs(rw, voff, p * 8 * K2 + s * 128, buf * STAGE_BYTES + A_BYTES + p * 1024);
+        }
+    };
+    const int swz = (q ^ ((r16 >> 1) & 7)) << 4;
+    const int xbase = (wm * 64 + r16) * 128 + swz, wbase = A_BYTES + (wn * 96 + r16) * 128 + swz;
+    auto load_x = [&](bf16x8 &f, int mt, int buf, int kk) { f = lds_ld128((xbase ^ (kk << 6)) + buf * STAGE_BYTES + mt * 2048); };
+    auto load_w = [&](bf16x8 &f, int nt, int buf, int kk) { f = lds_ld128((wbase ^ (kk << 6)) + buf * STAGE_BYTES + nt * 2048); };
+
+    f32x4 acc[6][4];
+#pragma unroll
+    for (int nt = 0; nt < 6; nt++)
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++) acc[nt][mt] = f32x4{ 0.f, 0.f, 0.f, 0.f };
+
+#pragma unroll
+    for (int j = 0; j < 7; j++) stage_piece(0, 0, j);
+#pragma unroll
+    for (int j = 0; j < 7; j++) stage_piece(nst > 1 ? 1 : 0, 1, j);
+    bf16x8 fw[2][6], fx[2][4];
+    barrier_dma();
+#pragma unroll
+    for (int nt = 0; nt < 6; nt++) load_w(fw[0][nt], nt, 0, 0);
+#pragma unroll
+    for (int mt = 0; mt < 4; mt++) load_x(fx[0][mt], mt, 0, 0);
+
+    // one stage = 2 K-steps of 32; buffer = stage parity (compile-time inside the pair)
+    auto stage = [&](int s, auto bufc) {
+        constexpr int buf = decltype(bufc)::value;
+#pragma unroll
+        for (int kk = 0; kk < 2; kk++) {
+            const int cur = kk;
+#pragma unroll
+            for (int n = 0; n < 6; n++) {                            // weight tile n: 4 MFMAs
+                // next K-step's fragments: kk == 0 from this stage; kk == 1 from the stage the barrier (behind tile 0)
+                // has just published, together with the refill of this buffer two stages ahead
+                if (kk == 0) {
+                    load_w(fw[1][n], n, buf, 1);
+                    if (n < 4) load_x(fx[1][n], n, buf, 1);
+                } else if (n >= 1) {
+                    load_w(fw[0][n - 1], n - 1, buf ^ 1, 0);
+                    if (n < 5) load_x(fx[0][n - 1], n - 1, buf ^ 1, 0);
+                    const int s2 = s + 2 < nst ? s + 2 : nst - 1;     // (the last two stages refetch the final one: no branch)
+                    stage_piece(s2, buf, n - 1);
+                    if (n >= 4) stage_piece(s2, buf, n + 1);          // pieces 5, 6 ride with tiles 4, 5
+                }
+#pragma unroll
+                for (int mt = 0; mt < 4; mt++)
+                    acc[n][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[cur][n], fx[cur][mt], acc[n][mt], 0, 0, 0);
+                const int nrd = kk == 0 ? (n < 4 ? 2 : 1) : (n == 0 ? 0 : n < 5 ? 2 : 1);
+                if (nrd == 2) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                else if (nrd == 1) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (kk == 1 && n >= 4) __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+                else if (kk == 1 && n >= 1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+                if (kk == 1 && n == 0) {
+                    // tile 0's MFMAs have consumed... (weight fragment 0 only; the other fragments of this buffer are
+                    // in registers too: every read of the K-step was issued during the previous one and LDS returns
+                    // in order) -> wait for them explicitly, then retire the buffer
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_waitcnt(0x0070);               // vmcnt(0) lgkmcnt(0)
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            if (kk == 1) {                                            // last weight fragment of the next stage
+                load_w(fw[0][5], 5, buf ^ 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+        }
+    };
+    using b0 = std::integral_constant<int, 0>;
+    using b1 = std::integral_constant<int, 1>;
+    int s = 0;
+    for (; s + 1 < nst; s += 2) {
+        stage(s, b0{});
+        stage(s + 1, b1{});
+    }
+    if (s < nst) stage(s, b0{});
+    __builtin_amdgcn_s_waitcnt(0x0F70);                               // no LDS-DMA may outlive the workgroup's LDS
+
+    // epilogue: + bias, bf16, 8-byte stores (lane: row m, 4 consecutive columns)
+#pragma unroll
+    for (int nt = 0; nt < 6; nt++) {
+        const int n = n0 + wn * 96 + nt * 16 + 4 * q;
+        const f32x4 b4 = *reinterpret_cast<const f32x4 *>(P.bias + n);
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++) {
+            const int m = m0 + wm * 64 + mt * 16 + r16;
+            const f32x4 v = acc[nt][mt];
+            const uint2 pk = make_uint2(pack_bf16x2(v[0] + b4[0], v[1] + b4[1]), pack_bf16x2(v[2] + b4[2], v[3] + b4[3]));
+            if (m < P.M) *reinterpret_cast<uint2 *>(P.out + (size_t)m * P.N + n) = pk;
+        }
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------
+// Value head behind the 1x1 convolution (neural_network.py:43-45,66-69): v = tanh(fc2(relu(fc1(hv)))).
+// 184 KB of fc1 weights, 92 kMAC per row: one wave per 16 rows, fragments straight from global memory
+// (L2-resident weights, each activation byte read once), 8 x 23 MFMAs, the 128 hidden units stay in the
+// accumulators (fp32, no bf16 round trip), fc2 is a 32-term dot product per lane + 2 shuffles.
+// K = 720 is padded to 736 = 23 x 32 in the WEIGHTS (zero columns); the activation operand of those 16
+// columns is whatever follows the row (finite bf16: the next row, or the caller's 32-byte slack after the
+// last row) and meets a zero weight.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_value_head(const uint16_t *__restrict__ hv, const uint16_t *__restrict__ w1,
+                                                    const float *__restrict__ b1, const float *__restrict__ w2,
+                                                    const float *__restrict__ b2, uint16_t *__restrict__ out, int M)
+{
+    constexpr int K = 720, KP = 736;
+    const int lane = threadIdx.x & 63, r16 = lane & 15, q = lane >> 4;
+    const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;
+    if (row0 >= M) return;
+    const int row = row0 + r16 < M ? row0 + r16 : M - 1;
+    const uint16_t *xr = hv + (size_t)row * K + q * 8;
+    const uint16_t *wr = w1 + (size_t)r16 * KP + q * 8;
+    f32x4 acc[8];
+#pragma unroll
+    for (int nt = 0; nt < 8; nt++) acc[nt] = *reinterpret_cast<const f32x4 *>(b1 + nt * 16 + 4 * q);
+#pragma unroll 1
+    for (int ks = 0; ks < KP / 32; ks++) {
+        const bf16x8 x = *reinterpret_cast<const bf16x8 *>(xr + ks * 32);
+#pragma unroll
+        for (int nt = 0; nt < 8; nt++) {
+            const bf16x8 w = *reinterpret_cast<const bf16x8 *>(wr + (size_t)nt * 16 * KP + ks * 32);
+            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, x, acc[nt], 0, 0, 0);     // D[hidden unit][row]
+        }
+    }
+    float part = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < 8; nt++) {
+        const f32x4 c = *reinterpret_cast<const f32x4 *>(w2 + nt * 16 + 4 * q);
+#pragma unroll
+        for (int i = 0; i < 4; i++) part += fmaxf(acc[nt][i], 0.f) * c[i];
+    }
+    part += __shfl_xor(part, 16, 64);
+    part += __shfl_xor(part, 32, 64);
+    if (q == 0 && row0 + r16 < M) {
+        const float v = tanhf(part + b2[0]);
+        out[row0 + r16] = (uint16_t)(pack_bf16x2(v, 0.f) & 0xffffu);
+    }
+}
+
+}  // namespace
+
+/* logits = act . w^T + bias on the engine's stream.  K % 64 == 0, N % 192 == 0 (pad the weight rows). */
+extern "C" int xq_policy_fc_bf16(void *stream, const void *act, const void *w, const void *bias, void *out, int M, int N, int K)
+{
+    if (!act || !w || !bias || !out || M <= 0 || N <= 0 || K < 64 || (K & 63) || N % BN) return XQ_E_INVALID;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_policy_fc), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                FC_LDS_BYTES) != hipSuccess)
+            return XQ_E_HIP;
+        attr_set = true;
+    }
+    FcArgs a{ (const uint16_t *)act, (const uint16_t *)w, (const float *)bias, (uint16_t *)out, M, N, K, N / BN };
+    const int ntiles = ((M + BM - 1) / BM) * (N / BN);
+    hipLaunchKernelGGL(k_policy_fc, dim3(ntiles), dim3(512), FC_LDS_BYTES, reinterpret_cast<hipStream_t>(stream), a);
+    return hipGetLastError() == hipSuccess ? 0 : XQ_E_HIP;
+}
+
+/* values[m] = tanh(w2 . relu(w1 . hv[m] + b1) + b2): hv [n_rows][720] bf16 with >= 32 readable bytes behind the last
+ * row, w1 [128][736] bf16 (columns 720.. zero), b1 / w2 float32[128], b2 float32[1], values bf16[n_rows]. */
+extern "C" int xq_value_head_bf16(void *stream, const void *hv, const void *w1, const void *b1, const void *w2, const void *b2,
+                                  void *values, int n_rows)
+{
+    if (!hv || !w1 || !b1 || !w2 || !b2 || !values || n_rows <= 0) return XQ_E_INVALID;
+    hipLaunchKernelGGL(k_value_head, dim3((n_rows + 63) / 64), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       (const uint16_t *)hv, (const uint16_t *)w1, (const float *)b1, (const float *)w2, (const float *)b2,
+                       (uint16_t *)values, n_rows);
+    return hipGetLastError() == hipSuccess ? 0 : XQ_E_HIP;
+}

@@ -597,6 +597,11 @@ __global__ __launch_bounds__(256, 2) void k_tower16(TowerArgs A)
             }
         }
         if (layer < 28) stamp(3 + 2 * layer);
+        // Round 2: the last stage barrier of a layer sits at the top of K-step 3 of tap 8,
+        // and this build still fetches that K-step's activation fragments of tiles 2..5 behind it, so without
+        // this barrier the partner wave of a board could start its in-place epilogue while those reads are
+        // in flight.  (k_tower16b closes the window structurally, without an extra barrier.)
+        __syncthreads();
         if (layer & 1) epilogue(BIAS + ((layer + 1) & 1) * 512, yes{}, yes{});
         else epilogue(BIAS + ((layer + 1) & 1) * 512, no{}, no{});
         barrier_dma();
@@ -665,9 +670,367 @@ __global__ __launch_bounds__(256, 2) void k_tower16(TowerArgs A)
     stamp(61);
 }
 
+
+// ------------------------------------------------------------------------------------------
+// k_tower16b — the 16x16x32 trunk with its issue stream rebuilt around what k_tower16's ISA showed
+// (round 2; k_tower16 stays selectable for A/B runs).  Same workgroup, tile, LDS image, weight
+// stream and numerics contract; what changed, each aimed at a wave's speed when it has the SIMD
+// to itself (k_tower16: 21.0 k cycles per layer against 13.8 k of MFMA issue):
+//   * the tap loop of a layer is fully unrolled (36 K-steps), so every `s_waitcnt lgkmcnt` is an
+//     exact count: the rolled loop drained the LDS queue at its back edge and again mid-K-step,
+//     right behind reads it had just issued;
+//   * activation fragments are double-buffered by K-step (all 6 of K-step k+1 are fetched during
+//     K-step k: 24 MFMAs of distance instead of 8).  The 48 registers come from the skip
+//     connection, which no longer lives in registers: the first convolution of a block re-reads
+//     the block input x from the LDS rows its epilogue is about to overwrite (same lane, same
+//     address) and starts the second convolution's accumulators at x + bias.  Every layer's bias
+//     enters through the accumulator initialisation, so an epilogue is cvt / ReLU / store only;
+//   * stage barriers are raw s_barrier + vmcnt(0) (no LDS drain), placed behind the first pixel
+//     tile of a stage's second K-step: its 4 MFMAs consume all 4 weight fragments of the retiring
+//     buffer, so each wave's reads of that buffer are complete when it arrives.  The last stage
+//     barrier of a layer also waits lgkmcnt(0): every activation read of the layer has been
+//     issued before it (none follow), so no wave can start its in-place epilogue while another
+//     still reads the layer input — the window k_tower16 left open;
+//   * tap addresses: row validity is kept as wave-uniform lane masks (SGPR pairs), the pixel-tile
+//     offset rides in the ds_read immediate and the swizzle term is shared by the 6 tiles:
+//     ~13 VALU per tap instead of ~54.
+// ------------------------------------------------------------------------------------------
+template <bool STAMP, int ABL = 0>
+__global__ __launch_bounds__(256, 2) void k_tower16b(TowerArgs A)
+{
+    constexpr int ACT0 = 2 * WBUF_BYTES, ZROW = ACT0 + 2 * ACT_BYTES, BIAS = ZROW + 256;   // bias: [2][128] f32
+
+    auto stamp = [&](int slot) {
+        if constexpr (STAMP) {
+            const unsigned long long t = __builtin_amdgcn_s_memtime();
+            if (threadIdx.x == 0) A.stamps[(size_t)blockIdx.x * 64 + slot] = t;
+            if (slot == 0 || slot == 61) {
+                const unsigned long long rt = __builtin_amdgcn_s_memrealtime();
+                if (threadIdx.x == 0) A.stamps[(size_t)blockIdx.x * 64 + (slot == 0 ? 62 : 63)] = rt;
+            }
+        }
+    };
+    stamp(0);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wb_ = wave >> 1, hc = wave & 1;                         // board in workgroup, channel half
+    const int board = blockIdx.x * 2 + wb_;
+    const bool board_ok = board < A.G;
+    const int act_off = ACT0 + wb_ * ACT_BYTES;
+    const int r16 = lane & 15, q = lane >> 4;
+
+    f32x4 acc[4][6];
+
+    // ---------------------------------------------------------------- input conv (16 -> 128)
+    // as in k_tower16 (all 9 tap slices staged at once, planes in the tail of the activation region);
+    // the accumulators start at this layer's bias
+    const int pl_off = act_off + ACT_BYTES - PIX * 32;
+    if (tid < 16) lds_st128(ZROW + tid * 16, make_uint4(0, 0, 0, 0));
+    const int nlayers = 2 * A.nblocks, nstages = nlayers * 18;
+    if (wave == 1 && lane < 32 && nstages > 0) dma16_abs(A.bias + 128 + lane * 4, BIAS + 512);   // bias[1] -> slot 1
+#pragma unroll
+    for (int j = 0; j < 9; j++) {
+        const int piece = wave * 9 + j;
+        dma16_abs(reinterpret_cast<const uint8_t *>(A.w1) + piece * 1024 + lane * 16, piece * 1024);
+    }
+    if (board_ok) {
+        const uint8_t *src = reinterpret_cast<const uint8_t *>(A.planes) + (size_t)board * PIX * 32;
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int q0 = (j * 2 + hc) * 64, idx = q0 + lane;
+            if (idx < PIX * 2) dma16_abs(src + idx * 16, pl_off + q0 * 16);
+        }
+    }
+#pragma unroll
+    for (int mt = 0; mt < 4; mt++) {
+        const f32x4 b4 = *reinterpret_cast<const f32x4 *>(A.bias + hc * 64 + mt * 16 + 4 * q);
+#pragma unroll
+        for (int nt = 0; nt < 6; nt++) acc[mt][nt] = b4;
+    }
+    barrier_dma();
+    {
+        uint32_t vm[2] = { 0, 0 };        // tap validity of the 6 pixels of this lane, 9 bits each
+#pragma unroll
+        for (int nt = 0; nt < 6; nt++) {
+            const int o = nt * 16 + r16;
+            uint32_t m = 0;
+            if (o < PIX) {
+                const int yy = o / 9, xx = o % 9;
+#pragma unroll
+                for (int t = 0; t < 9; t++) {
+                    const int dy = t / 3 - 1, dx = t % 3 - 1;
+                    if (yy + dy >= 0 && yy + dy < 10 && xx + dx >= 0 && xx + dx < 9) m |= 1u << t;
+                }
+            }
+            vm[nt / 3] |= m << ((nt % 3) * 9);
+        }
+#pragma unroll
+        for (int pair = 0; pair < 5; pair++) {                       // K-step = taps (2 pair, 2 pair + 1) x 16 planes
+            const int tap = 2 * pair + (q >> 1);
+            const bool tap_real = tap < 9;
+            const int tp = tap_real ? tap : 8;
+            const int off = (tp / 3 - 1) * 9 + (tp % 3 - 1);
+            bf16x8 bf[6], af[4];
+#pragma unroll
+            for (int nt = 0; nt < 6; nt++) {
+                const bool ok = tap_real && ((vm[nt / 3] >> ((nt % 3) * 9 + tp)) & 1u);
+                const int sp = nt * 16 + r16 + off;
+                bf[nt] = lds_ld128((ok ? pl_off + sp * 32 : ZROW + (sp & 7) * 32) + (q & 1) * 16);
+            }
+#pragma unroll
+            for (int mt = 0; mt < 4; mt++)
+                af[mt] = lds_ld128((tp * COUT + hc * 64 + mt * 16 + r16) * 32 + (q & 1) * 16);
+#pragma unroll
+            for (int nt = 0; nt < 6; nt++)
+#pragma unroll
+                for (int mt = 0; mt < 4; mt++)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mt], bf[nt], acc[mt][nt], 0, 0, 0);
+        }
+    }
+    barrier_dma();                                                 // every wave is done with planes and tap slices
+    stamp(1);
+
+    // weight stream of the 128-channel layers: as in k_tower16 (stage g -> buffer g & 1)
+    const rsrc_t wrsrc = make_rsrc(A.wt, nlayers * 9 * COUT * COUT * 2);
+    const int wsrc_even = (lane >> 3) * 256 + (((lane & 7) ^ (lane >> 4)) << 4), wsrc_odd = wsrc_even ^ 64;
+    auto stage_piece = [&](int g, int buf, int j) {
+        const int soff = (g >> 1) * (COUT * COUT * 2) + (g & 1) * 128 + (wave * 4 + j) * 2048;
+        dma16_buf_abs(wrsrc, (j & 1) ? wsrc_odd : wsrc_even, soff, buf * WBUF_BYTES + (wave * 4 + j) * 1024);
+    };
+    // A fragment (weight tile mt, K-step kk of a stage): abase ^ (kk << 6), + mt * 2048
+    const int abase = (hc * 64 + r16) * 128 + ((q ^ ((r16 >> 1) & 7)) << 4);
+    auto load_a1 = [&](bf16x8 &af, int mt, int sl, int kk) {
+        af = lds_ld128((abase ^ (kk << 6)) + sl * WBUF_BYTES + mt * 2048);
+    };
+
+    // row validity as lane masks (wave-uniform, SGPR pairs): pixel tile nt, lane -> pixel nt * 16 + r16.
+    // Only tile 0 holds board row 0, only tile 5 holds board row 9 and the 6 slots past pixel 89.
+    bool xl[6], xr[6];
+#pragma unroll
+    for (int nt = 0; nt < 6; nt++) {
+        const int p = nt * 16 + r16, xx = p % 9;
+        xl[nt] = xx != 0 && p < PIX;
+        xr[nt] = xx != 8 && p < PIX;
+    }
+    const bool real5 = r16 < PIX - 80, yu0 = r16 >= 9, yd5 = r16 == 0;
+    // row address of (pixel tile nt, tap), before the K-step term and without nt * 4096 (ds_read immediate):
+    //   real pixel : act_off + sp * 256 + slot,  sp = r16 + tap offset (tile-independent: 16 | nt * 16)
+    //   padding    : the zero row at the slot the lane's own row would have used (conflict-free groups)
+    const int Rrow = act_off + r16 * 256, r5 = r16 << 5, q4 = q << 4;
+    auto tap_addrs = [&](int (&as)[6], int tap) {
+        if (ABL & 4) tap = 4;
+        const int dy = tap / 3 - 1, dx = tap % 3 - 1, off = dy * 9 + dx;
+        // The addresses do not depend on the layer: left alone, the compiler computes all 54 ahead of the
+        // layer loop and spills them (each reload then waits vmcnt(0) in the middle of the MFMA stream, a
+        // full memory round trip that also drains the weight DMA).  An opaque copy of the row base per
+        // call keeps the ~13 VALU instructions of a tap where they are written.
+        int rrow = Rrow;
+        asm volatile("" : "+v"(rrow));
+        const int slot = ((r5 + off * 32) & 0xE0) ^ q4;              // ((q ^ ((sp & 7) << 1)) << 4)
+        const int aok = rrow + off * 256 + slot;
+#pragma unroll
+        for (int nt = 0; nt < 6; nt++) {
+            const bool sel = dx != 0 || (nt == 0 && dy < 0) || nt == 5;
+            if (!sel) { as[nt] = aok; continue; }
+            bool ok = dx < 0 ? xl[nt] : dx > 0 ? xr[nt] : real5;    // (dx == 0 needs a select for tile 5 and for tile 0 / row 0)
+            if (dx == 0 && nt == 0) ok = yu0;
+            else if (nt == 0 && dy < 0) ok = ok && yu0;
+            if (nt == 5 && dy > 0) ok = ok && yd5;
+            as[nt] = ok ? aok : slot + (ZROW - nt * 4096);
+        }
+    };
+    auto load_b1 = [&](bf16x8 &bf, int a, int nt, int ks) { bf = lds_ld128((a ^ (ks << 6)) + nt * 4096); };
+
+    // epilogue of one layer: acc (bias [+ skip] already inside) -> bf16 -> ReLU -> LDS rows in place;
+    // READ_X (first convolution of a block): the block input x is read back from those rows first and
+    // the next layer's accumulators start at x + bias; otherwise they start at the next layer's bias
+    auto epilogue = [&](auto read_x, int lb_next) {
+        if (ABL & 16) __builtin_amdgcn_s_setprio(3);
+        int ln;                                                       // lane id, 2 VALU, not CSE-able (see k_tower16)
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
+        const int r = ln & 15, qq = ln >> 4;
+        int sb[6];
+#pragma unroll
+        for (int nt = 0; nt < 6; nt++) {
+            const int p = nt * 16 + r < PIX ? nt * 16 + r : 0;
+            sb[nt] = act_off + p * 256 + (qq & 1) * 8 + (((hc * 8 + (qq >> 1)) ^ ((p & 7) << 1)) << 4);
+        }
+        const int lbq = lb_next + (hc * 64 + 4 * qq) * 4;
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++) {
+            const f32x4 bn = lds_ldf4(lbq + mt * 64);
+#pragma unroll
+            for (int nt = 0; nt < 6; nt++) {
+                const f32x4 v = acc[mt][nt];
+                const uint2 pk = make_uint2(relu_bf16x2(pack_bf16x2(v[0], v[1])), relu_bf16x2(pack_bf16x2(v[2], v[3])));
+                const int a = sb[nt] ^ (mt << 5);
+                if constexpr (decltype(read_x)::value) {
+                    const u32x2 x = lds_ld64(a);                                  // same lane, same address: ordered before the store
+                    acc[mt][nt] = f32x4{ bf16_lo(x.x) + bn[0], bf16_hi(x.x) + bn[1], bf16_lo(x.y) + bn[2], bf16_hi(x.y) + bn[3] };
+                } else acc[mt][nt] = bn;
+                if (nt < 5 || r < PIX - 80) lds_st64(a, pk);
+            }
+        }
+        if (ABL & 16) __builtin_amdgcn_s_setprio(0);
+    };
+    using yes = std::integral_constant<bool, true>;
+    using no = std::integral_constant<bool, false>;
+
+    if (nstages > 0) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) { stage_piece(0, 0, j); stage_piece(1, 1, j); }
+    }
+    epilogue(no{}, BIAS + 512);                                     // conv1 output; tower layer 0 starts at bias[1]
+    barrier_dma();
+    stamp(2);
+
+    // ---------------------------------------------------------------- residual tower
+    bf16x8 fa[2][4], fb[2][6];                                       // fragments, double-buffered by K-step parity
+    if (nstages > 0) {
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++) load_a1(fa[0][mt], mt, 0, 0);
+    }
+    for (int layer = 0; layer < nlayers; layer++) {
+        if (wave == 1 && lane < 32 && layer + 1 < nlayers)          // bias of tower layer L + 1 (row L + 2) -> slot L & 1
+            dma16_abs(A.bias + (size_t)(layer + 2) * 128 + lane * 4, BIAS + (layer & 1) * 512);
+        int as[6];
+        tap_addrs(as, 0);
+#pragma unroll
+        for (int nt = 0; nt < 6; nt++) load_b1(fb[0][nt], as[nt], nt, 0);
+#pragma unroll
+        for (int tap = 0; tap < 9; tap++) {
+            int asn[6];
+#pragma unroll
+            for (int ks = 0; ks < 4; ks++) {                        // 4 K-steps of 32 channels = 2 weight stages
+                const int sl = ks >> 1, kk = ks & 1, cur = ks & 1;
+                const int g = layer * 18 + tap * 2 + sl;
+                const bool last = tap == 8 && ks == 3;                // last K-step of the layer: no activation prefetch
+                if (ks == 3 && !last) tap_addrs(asn, tap + 1);
+#pragma unroll
+                for (int n = 0; n < 6; n++) {                        // pixel tile n: 4 MFMAs
+                    // the next K-step's activation fragment of this tile
+                    if (!last) {
+                        if (ks < 3) load_b1(fb[cur ^ 1][n], as[n], n, ks + 1);
+                        else load_b1(fb[cur ^ 1][n], asn[n], n, 0);
+                    }
+                    // the next K-step's weight fragments (kk == 1: from the stage the barrier just published)
+                    // and the refill of the retiring buffer two stages ahead
+                    if (kk == 0 && n < 4) load_a1(fa[cur ^ 1][n], n, sl, 1);
+                    if (kk == 1 && n >= 1 && n < 5) {
+                        load_a1(fa[cur ^ 1][n - 1], n - 1, sl ^ 1, 0);
+                        if (!(ABL & 1)) stage_piece(g + 2 < nstages ? g + 2 : nstages - 1, sl, n - 1);
+                    }
+#pragma unroll
+                    for (int mt = 0; mt < 4; mt++)
+                        acc[mt][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[cur][mt], fb[cur][n], acc[mt][n], 0, 0, 0);
+                    // issue order inside the tile: reads, first MFMA, DMA piece, the other MFMAs
+                    const int nrd = (last ? 0 : 1) + ((kk == 0 && n < 4) || (kk == 1 && n >= 1 && n < 5) ? 1 : 0);
+                    if (ABL & 32) {
+                        // one filler per MFMA gap: a 16-cycle MFMA leaves room for ~2 issue slots beside it, so two
+                        // reads, the m0 write and a DMA piece in ONE gap stall the matrix pipe
+                        if (nrd >= 1) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        if (nrd == 2) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        if (kk == 1 && n >= 1 && n < 5 && !(ABL & 1)) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    } else {
+                    if (nrd == 2) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    else if (nrd == 1) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    if (kk == 1 && n >= 1 && n < 5 && !(ABL & 1)) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+                    }
+                    if (kk == 1 && n == 0 && !(ABL & 2)) {
+                        // stage barrier: the next stage has landed (every wave drains its own pieces first) and,
+                        // this tile's MFMAs having consumed all 4 weight fragments of buffer sl, nobody reads it any more
+                        // (sched_barrier: the tile's MFMAs, and with them the waits for their operands, stay above)
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (ABL & 8) { }                                   // ablation: pieces are issued but never waited for
+                        else if (last) __builtin_amdgcn_s_waitcnt(0x0070); // vmcnt(0) lgkmcnt(0): + all activation reads done
+                        else __builtin_amdgcn_s_waitcnt(0x0F70);           // vmcnt(0)
+                        __builtin_amdgcn_s_barrier();
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+            if (tap < 8) {
+#pragma unroll
+                for (int nt = 0; nt < 6; nt++) as[nt] = asn[nt];
+            }
+        }
+        if (layer < 28) stamp(3 + 2 * layer);
+        if (layer & 1) epilogue(no{}, BIAS + (layer & 1) * 512);
+        else epilogue(yes{}, BIAS + (layer & 1) * 512);
+        barrier_dma();
+        if (layer < 28) stamp(4 + 2 * layer);
+    }
+
+    // ---------------------------------------------------------------- heads (1x1, 128 -> 32 + 8): as in k_tower16
+    {
+        const uint8_t *src = reinterpret_cast<const uint8_t *>(A.wh);     // [64][256 B], chunk ^ ((row & 7) << 1)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int q0 = (wave * 4 + j) * 64, idx = q0 + lane, row = idx >> 4, cp = idx & 15;
+            dma16_abs(src + row * 256 + ((cp ^ ((row & 7) << 1)) * 16), q0 * 16);
+        }
+    }
+    f32x4 hacc[2][6];
+#pragma unroll
+    for (int m = 0; m < 2; m++)
+#pragma unroll
+        for (int nt = 0; nt < 6; nt++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) hacc[m][nt][i] = 0.f;
+    barrier_dma();
+    const int nm = hc == 0 ? 2 : 1;                                  // policy: rows 0..31, value: rows 32..47
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) {
+        bf16x8 hb[6], ha[2];
+#pragma unroll
+        for (int nt = 0; nt < 6; nt++) {
+            const int p = nt * 16 + r16 < PIX ? nt * 16 + r16 : 0;
+            hb[nt] = lds_ld128(act_off + p * 256 + (((ks * 4 + q) ^ ((p & 7) << 1)) << 4));
+        }
+#pragma unroll
+        for (int m = 0; m < 2; m++) {
+            const int row = hc * 32 + m * 16 + r16;
+            ha[m] = lds_ld128(row * 256 + (((ks * 4 + q) ^ ((row & 7) << 1)) << 4));
+        }
+#pragma unroll
+        for (int m = 0; m < 2; m++)
+            if (m < nm)
+#pragma unroll
+                for (int nt = 0; nt < 6; nt++)
+                    hacc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ha[m], hb[nt], hacc[m][nt], 0, 0, 0);
+    }
+    stamp(60);
+    if (!board_ok) { stamp(61); return; }
+    uint8_t *Pb = reinterpret_cast<uint8_t *>(A.P) + (size_t)board * PIX * 64;
+    uint8_t *Vb = reinterpret_cast<uint8_t *>(A.V) + (size_t)board * PIX * 16;
+#pragma unroll
+    for (int m = 0; m < 2; m++) {
+        if (m >= nm) break;
+        const int c0 = hc * 32 + m * 16 + 4 * q;                     // head channel of element 0
+        const f32x4 b4 = *reinterpret_cast<const f32x4 *>(A.bh + c0);
+#pragma unroll
+        for (int nt = 0; nt < 6; nt++) {
+            const int p = nt * 16 + r16;
+            if (p < PIX && (hc == 0 || q < 2)) {                     // value head: channels 32..39 only
+                const float v0 = hacc[m][nt][0] + b4[0], v1 = hacc[m][nt][1] + b4[1];
+                const float v2 = hacc[m][nt][2] + b4[2], v3 = hacc[m][nt][3] + b4[3];
+                const uint2 pk = make_uint2(relu_bf16x2(pack_bf16x2(v0, v1)), relu_bf16x2(pack_bf16x2(v2, v3)));
+                if (hc == 0) *reinterpret_cast<uint2 *>(Pb + p * 64 + c0 * 2) = pk;
+                else *reinterpret_cast<uint2 *>(Vb + p * 16 + (c0 - 32) * 2) = pk;
+            }
+        }
+    }
+    stamp(61);
+}
+
 }  // namespace
 
-static int g_tower_variant = 1;     // 1 = k_tower16 (v_mfma_f32_16x16x32_bf16), 0 = k_tower (32x32x16)
+static int g_tower_variant = 2;     // 2 = k_tower16b (default), 1 = k_tower16, 0 = k_tower (32x32x16); 12..15 = ablations of 16b
 // diagnostic switch (not part of the public ABI): both kernels compute the same function
 extern "C" void xq_tower_set_variant(int v) { g_tower_variant = v; }
 
@@ -680,31 +1043,42 @@ static int launch_tower(void *stream, const void *planes, const void *w1, const 
         return XQ_E_INVALID;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tower<STAMP>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                LDS_BYTES) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tower16<STAMP>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                LDS_BYTES) != hipSuccess)
-            return XQ_E_HIP;
+        for (const void *f : { reinterpret_cast<const void *>(&k_tower<STAMP>), reinterpret_cast<const void *>(&k_tower16<STAMP>),
+                               reinterpret_cast<const void *>(&k_tower16b<STAMP>) })
+            if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) return XQ_E_HIP;
         if (STAMP)
             for (const void *f : { reinterpret_cast<const void *>(&k_tower16<true, 1>), reinterpret_cast<const void *>(&k_tower16<true, 2>),
-                                   reinterpret_cast<const void *>(&k_tower16<true, 3>), reinterpret_cast<const void *>(&k_tower16<true, 4>) })
+                                   reinterpret_cast<const void *>(&k_tower16<true, 3>), reinterpret_cast<const void *>(&k_tower16<true, 4>),
+                                   reinterpret_cast<const void *>(&k_tower16b<true, 1>), reinterpret_cast<const void *>(&k_tower16b<true, 2>),
+                                   reinterpret_cast<const void *>(&k_tower16b<true, 4>), reinterpret_cast<const void *>(&k_tower16b<true, 8>),
+                                   reinterpret_cast<const void *>(&k_tower16b<true, 16>), reinterpret_cast<const void *>(&k_tower16b<true, 32>),
+                                   reinterpret_cast<const void *>(&k_tower16b<true, 5>) })
                 if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) return XQ_E_HIP;
         attr_set = true;
     }
     TowerArgs a{ (const uint16_t *)planes, (const uint16_t *)w1, (const uint16_t *)wt, (const float *)bias,
                  (const uint16_t *)wh, (const float *)bh, (uint16_t *)policy_out, (uint16_t *)value_out, n_boards, n_blocks,
                  (unsigned long long *)stamps };
-    if (STAMP && g_tower_variant >= 2) {        // ablation builds ride on the stamp entry point
-        const dim3 grid((n_boards + 1) / 2), blk(256);
-        hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-        if (g_tower_variant == 5) hipLaunchKernelGGL((k_tower16<true, 4>), grid, blk, LDS_BYTES, st, a);
-        else if (g_tower_variant == 2) hipLaunchKernelGGL((k_tower16<true, 1>), grid, blk, LDS_BYTES, st, a);
-        else if (g_tower_variant == 3) hipLaunchKernelGGL((k_tower16<true, 2>), grid, blk, LDS_BYTES, st, a);
-        else hipLaunchKernelGGL((k_tower16<true, 3>), grid, blk, LDS_BYTES, st, a);
-    } else if (g_tower_variant)
-        hipLaunchKernelGGL(k_tower16<STAMP>, dim3((n_boards + 1) / 2), dim3(256), LDS_BYTES, reinterpret_cast<hipStream_t>(stream), a);
-    else
-        hipLaunchKernelGGL(k_tower<STAMP>, dim3((n_boards + 1) / 2), dim3(256), LDS_BYTES, reinterpret_cast<hipStream_t>(stream), a);
+    const dim3 grid((n_boards + 1) / 2), blk(256);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int v = g_tower_variant;
+    if (STAMP && v >= 3) {        // ablation builds (wrong results, timing only) ride on the stamp entry point
+        if (v == 3) hipLaunchKernelGGL((k_tower16<true, 1>), grid, blk, LDS_BYTES, st, a);          // k_tower16: no refills
+        else if (v == 4) hipLaunchKernelGGL((k_tower16<true, 2>), grid, blk, LDS_BYTES, st, a);     //            no stage barriers
+        else if (v == 5) hipLaunchKernelGGL((k_tower16<true, 3>), grid, blk, LDS_BYTES, st, a);     //            neither
+        else if (v == 6) hipLaunchKernelGGL((k_tower16<true, 4>), grid, blk, LDS_BYTES, st, a);     //            no tap arithmetic
+        else if (v == 12) hipLaunchKernelGGL((k_tower16b<true, 1>), grid, blk, LDS_BYTES, st, a);   // k_tower16b: no refills
+        else if (v == 13) hipLaunchKernelGGL((k_tower16b<true, 2>), grid, blk, LDS_BYTES, st, a);   //             no stage barriers
+        else if (v == 14) hipLaunchKernelGGL((k_tower16b<true, 4>), grid, blk, LDS_BYTES, st, a);   //             no tap arithmetic
+        else if (v == 15) hipLaunchKernelGGL((k_tower16b<true, 8>), grid, blk, LDS_BYTES, st, a);   //             refills never waited for
+        else if (v == 16) hipLaunchKernelGGL((k_tower16b<true, 16>), grid, blk, LDS_BYTES, st, a);  // option: s_setprio 3 in epilogues
+        else if (v == 17) hipLaunchKernelGGL((k_tower16b<true, 32>), grid, blk, LDS_BYTES, st, a);  // option: one filler per MFMA gap
+        else if (v == 18) hipLaunchKernelGGL((k_tower16b<true, 5>), grid, blk, LDS_BYTES, st, a);   // no refills, no tap arithmetic
+        else return XQ_E_INVALID;
+    } else if (v == 2) hipLaunchKernelGGL(k_tower16b<STAMP>, grid, blk, LDS_BYTES, st, a);
+    else if (v == 1) hipLaunchKernelGGL(k_tower16<STAMP>, grid, blk, LDS_BYTES, st, a);
+    else if (v == 0) hipLaunchKernelGGL(k_tower<STAMP>, grid, blk, LDS_BYTES, st, a);
+    else return XQ_E_INVALID;
     return hipGetLastError() == hipSuccess ? 0 : XQ_E_HIP;
 }
 

@@ -79,7 +79,7 @@ class CallbackEvaluator:
 class TorchNetEvaluator:
     """InferenceNet under PyTorch-ROCm; the search kernel writes its input planes in place."""
 
-    def __init__(self, net, dtype=None, channels_last=True, chunk=None, policy_columns="all", fused_tower=True):
+    def __init__(self, net, dtype=None, channels_last=True, chunk=None, policy_columns="reachable", fused_tower=True):
         import torch
         from .neural_network import InferenceNet
         self.torch = torch
@@ -93,9 +93,11 @@ class TorchNetEvaluator:
         else:
             raise ValueError("dtype must be bfloat16 or float32")
         self.channels_last = channels_last
+        # bf16 channels-last = the hand-written kernels; float32 (or NCHW) = PyTorch's library kernels, asked
+        # for explicitly by choosing that dtype / layout (parity runs against the fp32 reference)
         self.inet = net if isinstance(net, InferenceNet) else InferenceNet(
             net, dtype=dtype, c_in=16 if channels_last else 15, device="cuda", policy_columns=policy_columns,
-            fused_tower=fused_tower)
+            fused_tower=fused_tower, allow_library_fallback=(dtype != torch.bfloat16 or not channels_last))
         self.chunk = chunk
         self.kind = _lib.EVAL_LOGITS_BF16 if dtype == torch.bfloat16 else _lib.EVAL_LOGITS_F32
 

@@ -169,12 +169,16 @@ class InferenceNet(nn.Module):
     Output: (logits [G, 8100], values [G]) in `dtype`.
     """
 
-    def __init__(self, net, dtype=torch.bfloat16, c_in=16, device="cuda", policy_columns="all", fused_tower=True):
+    def __init__(self, net, dtype=torch.bfloat16, c_in=16, device="cuda", policy_columns="reachable", fused_tower=True,
+                 allow_library_fallback=False):
         super().__init__()
         self.dtype = dtype
         self.fused_tower = fused_tower                 # one launch for the whole trunk (csrc/xq_tower.hip)
         self.c_in = c_in
-        self.policy_columns = policy_columns           # "all" (reference layout) | "reachable" (opt-in)
+        # "reachable" (default): the policy FC computes only the 2,294 columns a legal move can index (the search
+        # gathers legal moves only, neural_network.py:148-169: every other logit is a dead output);
+        # "all": the reference's 8,100 columns (padded to the kernel's multiple of 192)
+        self.policy_columns = policy_columns
         convs = []
         w, b = _fold_bn(net.conv1, net.bn1)
         if c_in == 16:
@@ -192,6 +196,12 @@ class InferenceNet(nn.Module):
         # hand-written fused conv path: weights as [tap][cout][cin] bf16, bias fp32
         self.use_hip_conv = (dtype == torch.bfloat16 and c_in == 16 and str(device).startswith("cuda")
                              and net.conv1.out_channels == 128)
+        if not self.use_hip_conv and not allow_library_fallback:
+            # the hand-written kernels cover bf16, channels-last 16-plane input, 128 channels; anything else
+            # would run on library kernels (MIOpen / hipBLASLt): only on request, never silently
+            raise ValueError("InferenceNet: no hand-written HIP path for dtype=%s, c_in=%d, channels=%d, device=%s; "
+                             "pass allow_library_fallback=True to run this configuration on PyTorch's library kernels "
+                             "(parity / debugging runs only)" % (dtype, c_in, net.conv1.out_channels, device))
         self._buf = None
         self._hbuf = None
         self.tower_events = None
@@ -219,23 +229,43 @@ class InferenceNet(nn.Module):
         self.hb = nn.Parameter(hb.to(device=device, dtype=dtype), requires_grad=False)
         # policy FC consumes the NHWC-flattened activation: permute its input columns once
         # from (c, h, w) order (neural_network.py:62) to (h, w, c)
-        fcw = net.policy_fc.weight.detach().view(-1, 32, 90).permute(0, 2, 1).reshape(-1, 2880)
-        pfb = net.policy_fc.bias.detach()
-        self.column_map = None
+        fcw = net.policy_fc.weight.detach().cpu().view(-1, 32, 90).permute(0, 2, 1).reshape(-1, 2880)
+        pfb = net.policy_fc.bias.detach().cpu()
         if policy_columns == "reachable":
             cols, cmap = reachable_policy_columns()
-            pad = (-len(cols)) % 8                          # keep rows 16-byte aligned in bf16
-            idx = torch.from_numpy(np.concatenate([cols, np.zeros(pad, np.int64)]))
-            fcw, pfb = fcw[idx], pfb[idx]
-            self.column_map = cmap
+        elif policy_columns == "all":
+            cols, cmap = np.arange(8100, dtype=np.int64), None
+        else:
+            raise ValueError("policy_columns must be 'reachable' or 'all'")
+        # rows padded to the hand-written GEMM's column tile (192; zero weights, zero bias); the library path of
+        # the reference layout keeps exactly 8,100 columns
+        pad = (-len(cols)) % 192 if (self.use_hip_conv or cmap is not None) else 0
+        if pad and cmap is None:
+            cmap = np.arange(8100, dtype=np.int16)           # identity map: only the row stride differs
+        idx = torch.from_numpy(cols)
+        fcw, pfb = fcw[idx], pfb[idx]
+        if pad:
+            fcw = torch.cat([fcw, torch.zeros((pad, 2880), dtype=fcw.dtype)], 0)
+            pfb = torch.cat([pfb, torch.zeros(pad, dtype=pfb.dtype)], 0)
+        self.column_map = cmap
         self.n_policy = fcw.shape[0]
+        self.n_policy_real = len(cols)
         self.pfw = nn.Parameter(fcw.to(device=device, dtype=dtype).contiguous(), requires_grad=False)
         self.pfb = nn.Parameter(pfb.to(device=device, dtype=dtype), requires_grad=False)
-        v1 = net.value_fc1.weight.detach().view(-1, 8, 90).permute(0, 2, 1).reshape(-1, 720)
+        v1 = net.value_fc1.weight.detach().cpu().view(-1, 8, 90).permute(0, 2, 1).reshape(-1, 720)
         self.v1w = nn.Parameter(v1.to(device=device, dtype=dtype).contiguous(), requires_grad=False)
         self.v1b = nn.Parameter(net.value_fc1.bias.detach().to(device=device, dtype=dtype), requires_grad=False)
         self.v2w = nn.Parameter(net.value_fc2.weight.detach().to(device=device, dtype=dtype), requires_grad=False)
         self.v2b = nn.Parameter(net.value_fc2.bias.detach().to(device=device, dtype=dtype), requires_grad=False)
+        if self.use_hip_conv:
+            # hand-written FC kernels (csrc/xq_policy.hip): fp32 biases, value fc1 padded to K = 736
+            self.hip_pfb = pfb.to(device=device, dtype=torch.float32).contiguous()
+            v1p = torch.zeros((128, 736), dtype=v1.dtype)
+            v1p[:, :720] = v1
+            self.hip_v1w = v1p.to(device=device, dtype=dtype).contiguous()
+            self.hip_v1b = net.value_fc1.bias.detach().to(device=device, dtype=torch.float32).contiguous()
+            self.hip_v2w = net.value_fc2.weight.detach().reshape(128).to(device=device, dtype=torch.float32).contiguous()
+            self.hip_v2b = net.value_fc2.bias.detach().reshape(1).to(device=device, dtype=torch.float32).contiguous()
 
     def _tower_hip(self, x):
         """Residual tower on the hand-written fused conv kernel (csrc/xq_conv.hip): one launch per
@@ -270,9 +300,9 @@ class InferenceNet(nn.Module):
 
     def _head_buffers(self, g, device):
         if self._hbuf is None or self._hbuf[0].shape[0] != g:
-            self._hbuf = (torch.empty((g, 2880), dtype=torch.bfloat16, device=device),
-                          torch.empty((g, 720), dtype=torch.bfloat16, device=device))
-        return self._hbuf
+            flat = torch.zeros(g * 720 + 64, dtype=torch.bfloat16, device=device)   # slack: xq_value_head_bf16 reads 32 B past a row
+            self._hbuf = (torch.empty((g, 2880), dtype=torch.bfloat16, device=device), flat[:g * 720].view(g, 720), flat)
+        return self._hbuf[0], self._hbuf[1]
 
     def trunk_hip(self, x):
         """planes -> (policy-head activations [G, 2880], value-head activations [G, 720]) in one
@@ -326,8 +356,24 @@ class InferenceNet(nn.Module):
         return self._fc(hp, hv, g, out_logits, out_values)
 
     def _fc(self, hp, hv, g, out_logits, out_values):
+        if self.use_hip_conv and hp.is_cuda:
+            # hand-written FC kernels (csrc/xq_policy.hip): fixed accumulation order, no library GEMM
+            from . import _lib
+            L = _lib.lib()
+            st = torch.cuda.current_stream().cuda_stream
+            if out_logits is None:
+                out_logits = torch.empty((g, self.n_policy), dtype=torch.bfloat16, device=hp.device)
+            if out_values is None:
+                out_values = torch.empty((g,), dtype=torch.bfloat16, device=hp.device)
+            assert out_logits.is_contiguous() and out_logits.shape == (g, self.n_policy) and out_logits.dtype == torch.bfloat16
+            assert hp.is_contiguous() and hv.is_contiguous() and out_values.is_contiguous()
+            _lib.check(L.xq_policy_fc_bf16(st, hp.data_ptr(), self.pfw.data_ptr(), self.hip_pfb.data_ptr(),
+                                           out_logits.data_ptr(), g, self.n_policy, 2880))
+            _lib.check(L.xq_value_head_bf16(st, hv.data_ptr(), self.hip_v1w.data_ptr(), self.hip_v1b.data_ptr(),
+                                            self.hip_v2w.data_ptr(), self.hip_v2b.data_ptr(), out_values.data_ptr(), g))
+            return out_logits, out_values
         if out_logits is not None:
-            policy = torch.addmm(self.pfb, hp, self.pfw.t(), out=out_logits)   # no extra 265 MB copy
+            policy = torch.addmm(self.pfb, hp, self.pfw.t(), out=out_logits)   # no extra copy of the logits
         else:
             policy = F.linear(hp, self.pfw, self.pfb)
         v = F.relu(F.linear(hv, self.v1w, self.v1b))

@@ -22,7 +22,14 @@ class InterruptedWithResults(Exception):
         super().__init__("Training interrupted by user")
 
 
-def _evaluator_for(network, fast=True):
+# Precision of the leaf evaluator when a CUDA eval-mode ChessNet is handed to the mirror API.  The reference
+# evaluates in fp32 (neural_network.py:112-115); "bf16" (default) runs the hand-written MFMA kernels with
+# eval-mode BatchNorm folded (priors within the tolerance tests/test_gpu_parity.py states next to its
+# measured error), "f32" runs PyTorch's fp32 library kernels on the same device (parity runs).
+INFERENCE_DTYPE = "bf16"
+
+
+def _evaluator_for(network, fast=True, inference_dtype=None):
     if isinstance(network, (HashNetEvaluator, CallbackEvaluator, TorchNetEvaluator)):
         return network
     if fast:
@@ -32,7 +39,10 @@ def _evaluator_for(network, fast=True):
             if isinstance(network, InferenceNet):
                 return TorchNetEvaluator(network, dtype=network.dtype, channels_last=network.c_in == 16)
             if isinstance(network, ChessNet) and next(network.parameters()).is_cuda and not network.training:
-                return TorchNetEvaluator(network, dtype=torch.bfloat16)
+                name = inference_dtype or INFERENCE_DTYPE
+                if name not in ("bf16", "f32"):
+                    raise ValueError("inference_dtype must be 'bf16' or 'f32'")
+                return TorchNetEvaluator(network, dtype=torch.bfloat16 if name == "bf16" else torch.float32)
         except ImportError:
             pass
     return CallbackEvaluator(network)
@@ -71,15 +81,18 @@ class MCTS:
         return {decode_move(moves[0, j]): int(visits[0, j]) for j in range(int(n[0]))}
 
 
-def _play_batch(network, num_games, temperature, num_simulations, opponent_network, seeds=None, uniforms=None):
+def _play_batch(network, num_games, temperature, num_simulations, opponent_network, seeds=None, uniforms=None,
+                inference_dtype=None, on_engine=None):
     sims = num_simulations if num_simulations else MCTS_SIMULATIONS
-    ev = _evaluator_for(network)
-    ev_b = _evaluator_for(opponent_network) if opponent_network is not None else None
+    ev = _evaluator_for(network, inference_dtype=inference_dtype)
+    ev_b = _evaluator_for(opponent_network, inference_dtype=inference_dtype) if opponent_network is not None else None
+    if ev_b is not None and getattr(ev_b, "planes_format", 0) != getattr(ev, "planes_format", 0):
+        raise ValueError("both networks must use the same planes format")      # (before any engine exists)
     eng = SelfPlayEngine(num_games, sims=sims, temperature=temperature, max_moves=MAX_MOVES,
                          opponent_mode=opponent_network is not None,
                          planes_format=getattr(ev, "planes_format", _lib.PLANES_NONE))
-    if ev_b is not None and getattr(ev_b, "planes_format", 0) != getattr(ev, "planes_format", 0):
-        raise ValueError("both networks must use the same planes format")
+    if on_engine is not None:
+        on_engine(eng)
     if seeds is None:
         seeds = np.random.randint(0, 2 ** 31 - 1, size=num_games).astype(np.uint32)
     try:

@@ -133,8 +133,10 @@ int  xq_engine_set_pow_table(xq_engine *e, const double *table_host, int n);
 int  xq_engine_new_games(xq_engine *e, const uint32_t *seeds_host);
 
 /* Optional compact policy layout for XQ_EVAL_LOGITS_*: eval_a rows hold n_columns logits and
- * map_host[move] (int16[8100]) gives the column of a move, -1 for moves that can never be legal.
- * NULL restores the reference layout (8100 columns, column = move index; neural_network.py:160). */
+ * map_host[move] (int16[8100]) gives the column of a move, -1 for moves that can never be legal
+ * (n_columns is the row stride: it may exceed 8100 when rows are padded, e.g. to xq_policy_fc_bf16's
+ * multiple of 192).  NULL restores the reference layout (8100 columns, column = move index;
+ * neural_network.py:160). */
 int  xq_engine_set_logit_columns(xq_engine *e, const int16_t *map_host, int n_columns);
 
 /* ---- opt-in search extensions with NO counterpart in the reference (BASELINE config C5) ----
@@ -258,6 +260,24 @@ int  xq_heads_nhwc_bf16(void *hip_stream, const void *x_dev, const void *w_dev, 
 int  xq_tower_nhwc_bf16(void *hip_stream, const void *planes_dev, const void *w1_dev, const void *wt_dev,
                         const void *bias_dev, const void *wh_dev, const void *bh_dev, void *policy_out_dev,
                         void *value_out_dev, int n_boards, int n_blocks);
+
+/* The policy head's fully-connected layer (neural_network.py:39,64: nn.Linear(32*10*9, 8100) applied to the
+ * flattened policy-conv activations): logits[m][n] = bias[n] + sum_k act[m][k] * w[n][k].
+ * act [n_rows][k] bf16 (the (h, w, c)-ordered output of xq_tower_nhwc_bf16 / xq_heads_nhwc_bf16), w [n_cols][k]
+ * bf16 (nn.Linear weight layout, input columns permuted to (h, w, c)), bias float32[n_cols], logits
+ * [n_rows][n_cols] bf16; all device pointers.  k % 64 == 0 and n_cols % 192 == 0 (pad w / bias with zero rows;
+ * the caller may also DROP rows of w: the search gathers legal-move logits only, neural_network.py:148-169,
+ * so a column no legal move can index is a dead output — see xq_engine_set_logit_columns).  fp32 accumulation
+ * in a fixed order: results do not depend on the launch, the tile position or n_rows. */
+int  xq_policy_fc_bf16(void *hip_stream, const void *act_dev, const void *w_dev, const void *bias_dev, void *logits_dev,
+                       int n_rows, int n_cols, int k);
+
+/* The value head behind its 1x1 convolution (neural_network.py:43-45,66-69): values[m] = tanh(fc2(relu(fc1(hv[m])))).
+ * hv [n_rows][720] bf16 ((h, w, c) order, as xq_tower_nhwc_bf16 writes it) with at least 32 readable bytes behind
+ * the last row; w1 [128][736] bf16 = value_fc1.weight with its input columns permuted to (h, w, c) and 16 zero
+ * columns appended; b1, w2 float32[128]; b2 float32[1]; values bf16[n_rows].  The hidden layer stays in fp32. */
+int  xq_value_head_bf16(void *hip_stream, const void *hv_dev, const void *w1_dev, const void *b1_dev, const void *w2_dev,
+                        const void *b2_dev, void *values_dev, int n_rows);
 
 /* ------------------------------------------------------------------------------------------
  * Replay buffer: device-resident mirror of trainer.py's ReplayBuffer

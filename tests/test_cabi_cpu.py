@@ -130,8 +130,11 @@ def test_chessnet_state_dict_keys_and_shapes():
     x = torch.randn(5, 15, 10, 9)
     with torch.no_grad():
         p0, v0 = small(x)
+    with pytest.raises(ValueError, match="allow_library_fallback"):     # never a silent library path
+        InferenceNet(small, dtype=torch.float32, c_in=15, device="cpu")
     for c_in in (15, 16):
-        inet = InferenceNet(small, dtype=torch.float32, c_in=c_in, device="cpu")
+        inet = InferenceNet(small, dtype=torch.float32, c_in=c_in, device="cpu", policy_columns="all",
+                            allow_library_fallback=True)
         xi = torch.nn.functional.pad(x, (0, 0, 0, 0, 0, 1)) if c_in == 16 else x
         xi = xi.contiguous(memory_format=torch.channels_last)
         p1, v1 = inet(xi)

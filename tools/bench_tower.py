@@ -36,11 +36,12 @@ def timeit(fn, it=20):
 
 
 fl = 2.0 * G * 90 * (16 * 9 * 128 + 2 * blocks * 128 * 9 * 128 + 128 * 40)
-for variant in (0, 1, 0, 1):
+NAMES = {0: "k_tower (32x32x16)", 1: "k_tower16 (16x16x32, round 1)", 2: "k_tower16b (16x16x32, round 2)"}
+for variant in (0, 1, 2, 1, 2):
     L.xq_tower_set_variant(variant)
     ms = timeit(lambda: L.xq_tower_nhwc_bf16(*args))
-    print("k_tower%s G=%d blocks=%d: %.3f ms  %.1f TFLOP/s" % ("16 (16x16x32)" if variant else " (32x32x16)", G, blocks, ms, fl / ms / 1e9))
-variant = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+    print("%s G=%d blocks=%d: %.3f ms  %.1f TFLOP/s" % (NAMES[variant], G, blocks, ms, fl / ms / 1e9))
+variant = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 L.xq_tower_set_variant(variant)
 print("stamps: variant %d" % variant)
 
@@ -48,14 +49,19 @@ fn = L.xq_tower_debug_stamps
 fn.argtypes = [C.c_void_p] * 9 + [C.c_int, C.c_int, C.c_void_p]
 nwg = (G + 1) // 2
 stamps = torch.zeros(nwg * 64, dtype=torch.int64, device="cuda")
-if variant == 1:
-    # ablation builds of k_tower16 (results are wrong on purpose): what the weight refills / stage barriers cost
-    for v, name in ((1, "stamped build"), (2, "no weight refills"), (3, "no stage barriers"), (4, "neither"),
-                    (5, "no per-tap address arithmetic")):
+if variant in (1, 2):
+    # ablation builds (results are wrong on purpose): what the weight refills / stage barriers / tap arithmetic cost
+    abl = (((1, "stamped build"), (3, "no weight refills"), (4, "no stage barriers"), (5, "neither"),
+            (6, "no per-tap address arithmetic")) if variant == 1 else
+           ((2, "stamped build"), (12, "no weight refills"), (13, "no stage barriers"), (14, "no per-tap address arithmetic"),
+            (15, "weight refills issued but never waited for"), (16, "OPTION s_setprio 3 in epilogues (results valid)"),
+            (17, "OPTION one filler per MFMA gap (results valid)"), (18, "no refills, no tap arithmetic"),
+            (2, "stamped build again")))
+    for v, name in abl:
         L.xq_tower_set_variant(v)
         ms = timeit(lambda: fn(*args, stamps.data_ptr()), it=10)
-        print("k_tower16 %s: %.3f ms" % (name, ms))
-    L.xq_tower_set_variant(1)
+        print("%s %s: %.3f ms" % (NAMES[variant].split()[0], name, ms))
+    L.xq_tower_set_variant(variant)
 for _ in range(2):
     fn(*args, stamps.data_ptr())
 torch.cuda.synchronize()
