@@ -58,23 +58,24 @@ def tree_bytes_per_descent(b=33.3, lvl=0.86):
 
 
 def pmc_traffic(kernel, G, S, blocks, fetch_factor=1.0):
-    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/r01*_pmc_kernels.json:
-    separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same workload, KB per launch).
+    """(HBM bytes per launch of `kernel`, where that number comes from).  The PMC counters cannot be read
+    from inside this process: the bytes come from the newest committed rocprofv3 pass over this same
+    workload (profiles/*_pmc_kernels.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs, KB per launch,
+    tools/run_profiles.sh), and the source file is named next to the number.
     fetch_factor = 2 for kernels that read with 16 B/lane coalesced accesses (gfx950 FETCH_SIZE
-    correction, MI355X_MICROARCH.md); None for configs that were not profiled."""
+    correction, MI355X_MICROARCH.md); (None, None) for configs that were not profiled."""
     if not (G == 16384 and S == 50 and blocks == 6):
-        return None
-    k = None
-    for name in ("r01g_pmc_kernels.json", "r01f_pmc_kernels.json", "r01d_pmc_kernels.json"):          # newest pass that has the kernel
+        return None, None
+    for name in ("r02_pmc_kernels.json", "r01g_pmc_kernels.json", "r01f_pmc_kernels.json", "r01d_pmc_kernels.json"):
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
-            k = json.load(open(path))["kernels"].get(kernel)
+            doc = json.load(open(path))
+            k = doc["kernels"].get(kernel)
             if k and "FETCH_SIZE_KB_mean_per_launch" in k and "WRITE_SIZE_KB_mean_per_launch" in k:
-                break
-            k = None
-    if not k:
-        return None
-    return (fetch_factor * k["FETCH_SIZE_KB_mean_per_launch"] + k["WRITE_SIZE_KB_mean_per_launch"]) * 1024.0
+                byt = (fetch_factor * k["FETCH_SIZE_KB_mean_per_launch"] + k["WRITE_SIZE_KB_mean_per_launch"]) * 1024.0
+                return byt, "profiles/%s (committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload%s; not measured in this run)" % (
+                    name, ", " + doc["note"] if doc.get("note") else "")
+    return None, None
 
 
 # ------------------------------------------------------------------------------------------
@@ -296,7 +297,7 @@ def run_rank(args):
     ev = TorchNetEvaluator(net, dtype=dtype, chunk=args.net_chunk or None, policy_columns=args.policy_columns,
                            fused_tower=bool(args.fused_tower))
     stream = torch.cuda.current_stream().cuda_stream
-    records = torch.zeros(G * _lib.MAX_PLIES * xd.RECORD_BYTES, dtype=torch.uint8, device="cuda")
+    records = torch.zeros((args.refill if args.refill else G) * _lib.MAX_PLIES * xd.RECORD_BYTES, dtype=torch.uint8, device="cuda")
 
     # time the network forward with events on its own (= the engine's) stream
     fw_events = []
@@ -311,13 +312,20 @@ def run_rank(args):
         fw_events.append((a, b))
         return out
 
+    TG = args.refill if args.refill else G                  # games per GPU and step
+    if args.refill and (args.refill < G or args.temp_cutoff or args.tree_reuse):
+        sys.exit("bench.py: --refill TOTAL needs TOTAL >= --games and no per-ply temperature schedule / tree reuse")
+
     def step(eng, base_seed, timed):
         ev.evaluate = timed_eval if timed else orig_eval
         ev.inet.tower_events = tower_events if timed else None
-        seeds = xd.game_seeds(base_seed, G * world, rank, world)
-        sched = (lambda ply: 1.0 if ply < args.temp_cutoff else 0.001) if args.temp_cutoff > 0 else None
-        eng.play(ev, seeds, read=False, temperature_schedule=sched)
-        eng.pack_samples(records.data_ptr())
+        seeds = xd.game_seeds(base_seed, TG * world, rank, world)
+        if args.refill:
+            step.outcomes, step.plies = eng.play_refill(ev, seeds, records.data_ptr())
+        else:
+            sched = (lambda ply: 1.0 if ply < args.temp_cutoff else 0.001) if args.temp_cutoff > 0 else None
+            eng.play(ev, seeds, read=False, temperature_schedule=sched)
+            eng.pack_samples(records.data_ptr())
         if use_dist:
             xd.all_gather_records(records)
 
@@ -348,26 +356,26 @@ def run_rank(args):
         saved = eng.max_moves
         if args.warmup_plies > 0:
             eng.max_moves = args.warmup_plies
-        step(eng, 7_000_000 + w * G * world, False)
+        step(eng, 7_000_000 + w * TG * world, False)
         eng.max_moves = saved
     sync()
     eng.profile(True)
     t0 = time.time()
     for k in range(args.steps):
-        step(eng, k * G * world, True)
+        step(eng, k * TG * world, True)
     sync()
     dt = time.time() - t0
     prof = eng.profile_read()
     fw_ms = sum(a.elapsed_time(b) for a, b in fw_events)
     n_fw = len(fw_events)
-    outcomes = eng.read_game_outcomes()
+    outcomes = step.outcomes if args.refill else eng.read_game_outcomes()
     t = torch.tensor([dt], dtype=torch.float64, device="cuda")
     if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
 
     if rank == 0:
-        games = G * world * args.steps
+        games = TG * world * args.steps
         rows = eng.n_rows                                   # network rows per forward (one per game; x8 slots with virtual loss)
         fl = net_flops_per_row(args.blocks)
         fl -= 2 * 2880 * (8100 - ev.inet.n_policy_real)        # only the policy columns actually computed count (no padding)
@@ -380,34 +388,42 @@ def run_rank(args):
         if fused:       # k_tower: conv1 + 2*blocks convs + both heads per launch
             n_conv = len(tower_events)
             conv_fl = 2.0 * rows * 90 * (16 * 9 * 128 + 2 * args.blocks * 128 * 9 * 128 + 128 * 40)
-            kname, kdesc = "k_tower", "k_tower16, hand-written single-launch trunk on v_mfma_f32_16x16x32_bf16: conv3x3(16->128) + %d fused residual convs + 1x1 heads, activations resident in LDS" % (2 * args.blocks)
+            kname, kdesc = "k_tower", "k_tower16b, hand-written single-launch trunk on v_mfma_f32_16x16x32_bf16: conv3x3(16->128) + %d fused residual convs + 1x1 heads, activations resident in LDS" % (2 * args.blocks)
         else:
             n_conv = 2 * args.blocks * len(tower_events)
             conv_fl = 2.0 * rows * 90 * 128 * 9 * 128
             kname, kdesc = "k_conv3x3_b<128>", "hand-written fused conv3x3+bias+residual+ReLU"
         conv_tflops = conv_fl * n_conv / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+        tr_tower = pmc_traffic(kname, G, S, args.blocks, fetch_factor=2.0) if rows == G else (None, None)
+        tr_tree = pmc_traffic("k_search_round", G, S, args.blocks)
+        extras = [", policy FC on the %d columns a legal move can index (of 8,100; the others are never read by the search "
+                  "and are not counted as work)" % ev.inet.n_policy_real if args.policy_columns == "reachable"
+                  else ", full 8,100-column policy FC"]
+        if args.root_noise or args.temp_cutoff:
+            extras.append(", Dirichlet root noise %s, temperature 1 -> 0 at ply %d (extensions, no reference oracle)"
+                          % (args.root_noise, args.temp_cutoff))
+        if args.tree_reuse:
+            extras.append(", tree reuse (extension)")
+        if args.virtual_loss:
+            extras.append(", virtual loss: %d rows per game and round (extension)" % (rows // G))
+        if args.refill:
+            extras.append("; REFILL mode: %d games per GPU and step through the %d slots, a finished game's slot restarted at "
+                          "once (steady state; reported beside the headline lock-step number, not instead of it)" % (args.refill, G))
+        workload = "%s%d concurrent games/GPU, %d sims, %d-block ResNet %s, random-init weights, start positions, seeds base+g%s" % (
+            "BASELINE configs[2]: " if (G, S, args.blocks) == (16384, 50, 6) and not args.refill else "",
+            G, S, args.blocks, args.dtype, "".join(extras))
         out = {
             "metric": "self-play games/sec @ 50 MCTS sims" if S == 50 else "self-play games/sec @ %d MCTS sims" % S,
             "value": games / dt, "unit": "games/s", "n_gpus": dist.get_world_size() if use_dist else 1, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic" if not args.profile_plies else
             "synthetic; PROFILING RUN truncated to %d plies per step - not a benchmark" % args.profile_plies,
-            "config": {"workload": "%s%d concurrent games/GPU, %d sims, %d-block ResNet %s, "
-                                   "random-init weights, start positions, seeds base+g%s" % (
-                                       "BASELINE configs[2]: " if (G, S, args.blocks) == (16384, 50, 6) else "",
-                                       G, S, args.blocks, args.dtype,
-                                       (", policy FC on the %d columns a legal move can index (of 8,100; the others are never "
-                                        "read by the search and are not counted as work)" % ev.inet.n_policy_real
-                                        if args.policy_columns == "reachable" else ", full 8,100-column policy FC") +
-                                       (", Dirichlet root noise %s, temperature 1 -> 0 at ply %d (extensions, no reference oracle)"
-                                        % (args.root_noise, args.temp_cutoff)) if (args.root_noise or args.temp_cutoff) else "") +
-                                       (", tree reuse (extension)" if args.tree_reuse else "") +
-                                       (", virtual loss: %d rows per game and round (extension)" % (rows // G) if args.virtual_loss else ""),
+            "config": {"workload": workload,
                        "games_per_gpu": G, "sims": S, "blocks": args.blocks, "max_moves": 70,
                        "parallelism": "games sharded x%d, all-gather of samples at step end" % world},
             "roofline": {"bound": "mfma", "achieved": conv_tflops, "peak": MFMA_PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": conv_tflops / MFMA_PEAK_BF16_TFLOPS,
-                         "traffic": pmc_traffic(kname, G, S, args.blocks, fetch_factor=2.0) if rows == G else None,
+                         "traffic": tr_tower[0], "traffic_source": tr_tower[1],
                          "kernel": "%s (%s; %d launches of %d boards, %.4f ms avg; %.0f%% of the step)" % (
                              kname, kdesc, n_conv, rows, conv_ms / max(n_conv, 1), 100.0 * conv_ms / (dt * 1e3)),
                          "flops_per_launch": conv_fl},
@@ -417,7 +433,7 @@ def run_rank(args):
                                  n_fw, rows, fw_ms / max(n_fw, 1)),
                              "flops_per_launch": fl * rows},
             "roofline_tree": {"bound": "hbm", "achieved": tree_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                              "frac": tree_gbs / HBM_PEAK_GBS, "traffic": pmc_traffic("k_search_round", G, S, args.blocks),
+                              "frac": tree_gbs / HBM_PEAK_GBS, "traffic": tr_tree[0], "traffic_source": tr_tree[1],
                               "kernel": "k_search_round (%d launches, %.3f ms avg)" % (
                                   prof["search_launches"], prof["search_ms"] / max(prof["search_launches"], 1)),
                               "bytes_per_launch": bpd * G},

@@ -139,6 +139,9 @@ _SIGNATURES = {
     "xq_engine_read_games": (C.c_int, [C.c_void_p] * 8),
     "xq_engine_read_samples": (C.c_int, [C.c_void_p] * 9),
     "xq_engine_pack_samples": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "xq_engine_refill_begin": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
+    "xq_engine_refill_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "xq_engine_refill_read_games": (C.c_int, [C.c_void_p] * 8),
     "xq_conv3x3_nhwc_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_int, C.c_int, C.c_int]),
     "xq_heads_nhwc_bf16": (C.c_int, [C.c_void_p] * 6 + [C.c_int]),

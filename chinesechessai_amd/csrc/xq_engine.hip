@@ -419,10 +419,10 @@ __device__ void init_board(int8_t *bd)
     }
 }
 
-__global__ __launch_bounds__(64) void k_new_games(Eng E)
+// ChineseChess.reset (chess_env.py:14-67) for the game in slot g, + the first root's move list
+__device__ void new_game(const Eng &E, int g, WaveLds &L)
 {
-    __shared__ WaveLds L;
-    const int g = blockIdx.x, lane = XQ_LANE;
+    const int lane = XQ_LANE;
     init_board(L.bd);
     wave_sync();
     BoardView v = load_view(L.bd);
@@ -438,6 +438,12 @@ __global__ __launch_bounds__(64) void k_new_games(Eng E)
     const int K = E.leaf_slots;
     for (int k = lane; k < K; k += 64) { E.leaf_node[(size_t)g * K + k] = LEAF_NONE; E.leaf_mult[(size_t)g * K + k] = 0; }
     if (lane == 0) E.root_node[g] = 0;
+}
+
+__global__ __launch_bounds__(64) void k_new_games(Eng E)
+{
+    __shared__ WaveLds L;
+    new_game(E, blockIdx.x, L);
 }
 
 // roots from caller-provided envs (one staged int8 board + int32 state row per game)
@@ -777,10 +783,9 @@ __global__ __launch_bounds__(64) void k_play_move(Eng E)
 }
 
 // self_play.py:259-310
-__global__ __launch_bounds__(64) void k_finalize(Eng E)
+__device__ void finalize_game(const Eng &E, int g, const GameS &gs)
 {
-    const int g = blockIdx.x, lane = XQ_LANE;
-    const GameS gs = load_gs(E.gs + g);
+    const int lane = XQ_LANE;
     const int winner = gs.winner == WINNER_NONE ? 0 : gs.winner;
     const int len = gs.n_samples;
     for (int i = lane; i < len; i += 64) {
@@ -796,13 +801,19 @@ __global__ __launch_bounds__(64) void k_finalize(Eng E)
     }
 }
 
-__global__ __launch_bounds__(64) void k_pack_samples(Eng E, xq_sample_record *rec)
+__global__ __launch_bounds__(64) void k_finalize(Eng E)
 {
-    const int g = blockIdx.x, lane = XQ_LANE;
-    const GameS gs = load_gs(E.gs + g);
+    const int g = blockIdx.x;
+    finalize_game(E, g, load_gs(E.gs + g));
+}
+
+// the samples of the game in slot g as fixed-size records rec[0 .. 69]
+__device__ void pack_game(const Eng &E, int g, const GameS &gs, xq_sample_record *rec)
+{
+    const int lane = XQ_LANE;
     for (int i = 0; i < XQ_MAX_PLIES; i++) {
         const size_t si = (size_t)g * XQ_MAX_PLIES + i;
-        xq_sample_record *r = rec + si;
+        xq_sample_record *r = rec + i;
         const bool valid = i < gs.n_samples;
         if (lane < 12) r->board[lane] = valid ? E.s_board[si * 12 + lane] : 0u;
         for (int j = lane; j < MAXM; j += 64) {
@@ -818,6 +829,51 @@ __global__ __launch_bounds__(64) void k_pack_samples(Eng E, xq_sample_record *re
             r->chosen = valid ? E.t_move[si] : 0;
         }
     }
+}
+
+__global__ __launch_bounds__(64) void k_pack_samples(Eng E, xq_sample_record *rec)
+{
+    const int g = blockIdx.x;
+    pack_game(E, g, load_gs(E.gs + g), rec + (size_t)g * XQ_MAX_PLIES);
+}
+
+// ------------------------------------------------------------------------------------------
+// Refill: the reference's pool hands a worker its next game the moment one ends (imap_unordered,
+// self_play.py:404-408).  Here a finished game's slot is retired into its own record block (z table + packed
+// samples + outcome, all by game id) and restarted on the next unplayed game id; a game's result depends only
+// on its seed (its private MT19937 doubles travel with the id), never on the slot or the ply it started at.
+// ------------------------------------------------------------------------------------------
+struct Refill {
+    const double *uni_all;     // [total][70]
+    int32_t *slot_game;        // [G]  game id in the slot, -1 = retired
+    int32_t *next_game;        // next unplayed game id
+    int32_t *active;           // out: slots still playing after this step
+    GameS *out_gs;             // [total]
+    xq_sample_record *records; // [total][70]
+    int total;
+};
+
+__global__ __launch_bounds__(64) void k_refill(Eng E, Refill R)
+{
+    __shared__ WaveLds L;
+    const int g = blockIdx.x, lane = XQ_LANE;
+    int id = R.slot_game[g];
+    if (id < 0) return;
+    const GameS gs = load_gs(E.gs + g);
+    if (!gs.done) { if (lane == 0) atomicAdd(R.active, 1); return; }
+    finalize_game(E, g, gs);
+    mem_fence_wave();
+    wave_sync();
+    pack_game(E, g, gs, R.records + (size_t)id * XQ_MAX_PLIES);
+    if (lane == 0) R.out_gs[id] = gs;
+    int nid = 0;
+    if (lane == 0) nid = atomicAdd(R.next_game, 1);
+    nid = uni(nid);
+    if (nid >= R.total) { if (lane == 0) R.slot_game[g] = -1; return; }
+    for (int j = lane; j < XQ_MAX_PLIES; j += 64)
+        E.uniforms[(size_t)g * XQ_MAX_PLIES + j] = R.uni_all[(size_t)nid * XQ_MAX_PLIES + j];
+    new_game(E, g, L);
+    if (lane == 0) { R.slot_game[g] = nid; atomicAdd(R.active, 1); }
 }
 
 // root children of every game (moves, visit counts, priors), zero-padded to 128
@@ -1076,6 +1132,9 @@ struct xq_engine {
     int32_t *stage_rvisits = nullptr;    // [G][128]
     float *stage_rpriors = nullptr;      // [G][128]
     int32_t *stage_rn = nullptr;         // [G]
+    // refill mode (xq_engine_refill_*)
+    double *uni_all = nullptr; int32_t *slot_game = nullptr, *next_game = nullptr; GameS *out_gs = nullptr;
+    int refill_total = 0;
     // profiling
     bool prof = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_search, ev_play;
@@ -1495,6 +1554,73 @@ extern "C" int xq_engine_finalize(xq_engine *e)
     HIPCHK(hipSetDevice(e->cfg.device));
     hipLaunchKernelGGL(k_finalize, dim3(e->E.G), dim3(64), 0, e->stream, e->E);
     HIPCHK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int xq_engine_refill_begin(xq_engine *e, const uint32_t *seeds, int total)
+{
+    if (!e || !seeds) return fail(XQ_E_INVALID, "null argument");
+    if (total < e->E.G) return fail(XQ_E_INVALID, "refill needs at least as many games as slots");
+    if (e->E.opponent_mode) return fail(XQ_E_INVALID, "refill is not available in opponent (arena) mode: slots are at different plies");
+    HIPCHK(hipSetDevice(e->cfg.device));
+    const size_t G = (size_t)e->E.G, T = (size_t)total;
+    if (total > e->refill_total) {           // (buffers of an earlier, smaller session stay in e->allocs until destroy)
+        if (dalloc(e, e->uni_all, T * XQ_MAX_PLIES) || dalloc(e, e->out_gs, T)) return fail(XQ_E_HIP, "hipMalloc failed");
+        e->refill_total = total;
+    }
+    if (!e->slot_game && (dalloc(e, e->slot_game, G) || dalloc(e, e->next_game, (size_t)1)))
+        return fail(XQ_E_HIP, "hipMalloc failed");
+    std::vector<double> u(T * XQ_MAX_PLIES);
+    for (size_t g = 0; g < T; g++) mt_uniforms(seeds[g], u.data() + g * XQ_MAX_PLIES, XQ_MAX_PLIES);
+    std::vector<int32_t> sg(G);
+    for (size_t g = 0; g < G; g++) sg[g] = (int32_t)g;
+    const int32_t next = (int32_t)G;
+    HIPCHK(hipMemcpyAsync(e->uni_all, u.data(), u.size() * 8, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(e->E.uniforms, e->uni_all, G * XQ_MAX_PLIES * 8, hipMemcpyDeviceToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(e->slot_game, sg.data(), G * 4, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(e->next_game, &next, 4, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemsetAsync(e->out_gs, 0, T * sizeof(GameS), e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));          // locals: the copies must finish
+    hipLaunchKernelGGL(k_new_games, dim3(e->E.G), dim3(64), 0, e->stream, e->E);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int xq_engine_refill_step(xq_engine *e, void *records, int32_t *active)
+{
+    if (!e || !records) return fail(XQ_E_INVALID, "null argument");
+    if (!e->slot_game || e->refill_total <= 0) return fail(XQ_E_INVALID, "xq_engine_refill_begin first");
+    HIPCHK(hipSetDevice(e->cfg.device));
+    HIPCHK(hipMemsetAsync(e->active_dev, 0, 4, e->stream));
+    Refill R{ e->uni_all, e->slot_game, e->next_game, e->active_dev, e->out_gs, (xq_sample_record *)records, e->refill_total };
+    hipLaunchKernelGGL(k_refill, dim3(e->E.G), dim3(64), 0, e->stream, e->E, R);
+    HIPCHK(hipGetLastError());
+    if (active) {
+        HIPCHK(hipMemcpyAsync(active, e->active_dev, 4, hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+    }
+    return 0;
+}
+
+extern "C" int xq_engine_refill_read_games(xq_engine *e, int32_t *winner, int32_t *reason, int32_t *reason_side,
+                                           int32_t *reason_count, int32_t *n_plies, int32_t *n_samples, int32_t *error)
+{
+    if (!e) return fail(XQ_E_INVALID, "null engine");
+    if (!e->out_gs || e->refill_total <= 0) return fail(XQ_E_INVALID, "xq_engine_refill_begin first");
+    HIPCHK(hipSetDevice(e->cfg.device));
+    const size_t T = (size_t)e->refill_total;
+    std::vector<GameS> gs(T);
+    HIPCHK(hipMemcpyAsync(gs.data(), e->out_gs, T * sizeof(GameS), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    for (size_t g = 0; g < T; g++) {
+        if (winner) winner[g] = gs[g].winner == WINNER_NONE ? 0 : gs[g].winner;       // self_play.py:259
+        if (reason) reason[g] = gs[g].reason;
+        if (reason_side) reason_side[g] = gs[g].reason_side;
+        if (reason_count) reason_count[g] = gs[g].reason_count;
+        if (n_plies) n_plies[g] = gs[g].n_plies;
+        if (n_samples) n_samples[g] = gs[g].n_samples;
+        if (error) error[g] = gs[g].error;
+    }
     return 0;
 }
 

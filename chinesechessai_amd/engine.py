@@ -314,6 +314,34 @@ class SelfPlayEngine:
         _lib.check(self.L.xq_engine_finalize(self.h))
         return self.read_results() if read else None
 
+    def play_refill(self, evaluator, seeds, records_ptr, check_every=4, max_plies=None):
+        """`len(seeds)` games through the engine's G slots with refill (xq_engine_refill_*): a finished game's
+        slot restarts on the next unplayed seed at once, like the reference's pool (self_play.py:404-408).
+        `records_ptr`: device buffer of len(seeds) * 70 sample records (distributed.RECORD_BYTES each), filled
+        by game id.  Returns the per-game outcome arrays (by game id) and the number of plies stepped."""
+        seeds = np.ascontiguousarray(seeds, dtype=np.uint32)
+        total = len(seeds)
+        evaluator.bind(self)
+        _lib.check(self.L.xq_engine_refill_begin(self.h, _lib.ptr(seeds), total))
+        active = np.zeros(1, np.int32)
+        plies = 0
+        cap = max_plies or (total // self.n_games + 2) * _lib.MAX_PLIES + 8
+        while plies < cap:
+            self.search(evaluator)
+            _lib.check(self.L.xq_engine_play_move(self.h))
+            poll = plies % check_every == check_every - 1
+            _lib.check(self.L.xq_engine_refill_step(self.h, C.c_void_p(records_ptr), _lib.ptr(active) if poll else None))
+            plies += 1
+            if poll and int(active[0]) == 0:
+                break
+        else:
+            raise _lib.XqError("play_refill: games still active after %d plies" % cap)
+        out = {k: np.zeros(total, np.int32) for k in ("winner", "reason", "reason_side", "reason_count", "n_plies",
+                                                      "n_samples", "error")}
+        _lib.check(self.L.xq_engine_refill_read_games(self.h, *[_lib.ptr(out[k]) for k in (
+            "winner", "reason", "reason_side", "reason_count", "n_plies", "n_samples", "error")]))
+        return out, plies
+
     def read_results(self):
         G, P, M = self.n_games, _lib.MAX_PLIES, _lib.MAX_MOVES
         b = GameBatch(G, self.temperature)

@@ -234,6 +234,21 @@ typedef struct {
 } xq_sample_record;
 int  xq_engine_pack_samples(xq_engine *e, void *records_dev /* xq_sample_record[G][70] */);
 
+/* ---- refill: `total` games through the engine's G concurrent slots, a finished game's slot being restarted
+ * on the next unplayed game at once — what the reference's pool does by construction (imap_unordered hands a
+ * worker its next game as soon as one ends, self_play.py:404-408).  A game's result depends only on
+ * seeds_host[id]: it is the game xq_engine_new_games would play for that seed, whatever slot and ply it
+ * starts at.  Protocol: refill_begin; then per ply { search rounds as usual; xq_engine_play_move;
+ * xq_engine_refill_step } until *active_host reads 0.  refill_step retires every finished game into
+ * records_dev[id][0..69] (z table applied, self_play.py:259-310) and its outcome into the table
+ * refill_read_games returns (same fields as xq_engine_read_games, indexed by game id 0..total-1), and
+ * restarts the slot.  active_host may be NULL (no host synchronisation in that step).  total >= G; not
+ * available in opponent mode (slots are at different plies). */
+int  xq_engine_refill_begin(xq_engine *e, const uint32_t *seeds_host /*[total]*/, int total);
+int  xq_engine_refill_step(xq_engine *e, void *records_dev /* xq_sample_record[total][70] */, int32_t *active_host);
+int  xq_engine_refill_read_games(xq_engine *e, int32_t *winner, int32_t *reason, int32_t *reason_side,
+                                 int32_t *reason_count, int32_t *n_plies, int32_t *n_samples, int32_t *error);
+
 /* ---- network: fused 3x3 convolution of the residual tower (neural_network.py:54,181-187 with the
  * eval-mode BatchNorm folded into weights and bias):
  *     y = relu?( conv3x3(x, w) + bias [+ residual] )

@@ -689,6 +689,94 @@ def test_full_size_properties(L):
             assert list(og.t_visits[i][:k]) == b.s_counts[g, i, :k].tolist()
 
 
+def test_refill_every_finished_game_equals_its_oracle_game(L):
+    """Refill (the reference's pool does it by construction, self_play.py:404-408): 10 games
+    through 4 slots at S = 50 with the exact evaluator.  Seed 2 is the golden game that ends by checkmate at ply
+    33 (tests/golden/search_hashnet.json); it is dealt four times so that slots restart at plies 33, 66, 70
+    and 103 while their neighbours are mid-game.  Every game — whatever slot and ply it started at — must be
+    the oracle's game for its seed, move for move, visit for visit, z bit for bit; and the batch must finish in
+    the plies the refill schedule predicts (140), not in 3 lock-step batches (210)."""
+    import struct
+    import torch
+    from chinesechessai_amd import distributed as xd
+    from chinesechessai_amd.engine import HashNetEvaluator, SelfPlayEngine
+    from oracle import xq_oracle as xo
+    seeds = np.array([2, 0, 1, 3, 2, 5, 2, 6, 7, 2], dtype=np.uint32)
+    G, S, T = 4, 50, len(seeds)
+    eng = SelfPlayEngine(G, sims=S)
+    rec_t = torch.zeros(T * 70 * xd.RECORD_BYTES, dtype=torch.uint8, device="cuda")
+    out, plies = eng.play_refill(HashNetEvaluator(), seeds, rec_t.data_ptr(), check_every=1)
+    rec = xd.records_to_numpy(rec_t).reshape(T, 70)
+    eng.close()
+    assert (out["error"] == 0).all()
+    oracle = {}
+    for i, seed in enumerate(seeds):
+        if int(seed) not in oracle:
+            rc, og = xo.self_play_game(int(seed), S)
+            assert rc == 0
+            oracle[int(seed)] = og
+        og = oracle[int(seed)]
+        assert (out["winner"][i], out["reason"][i], out["n_plies"][i], out["n_samples"][i]) == (
+            og.winner, og.end_reason, og.n_plies, og.n_samples), (i, seed)
+        assert int(rec[i]["valid"].sum()) == og.n_samples and rec[i]["valid"][:og.n_samples].all()
+        for j in range(og.n_samples):
+            k = og.s_nmoves[j]
+            assert int(rec[i, j]["n_moves"]) == k and int(rec[i, j]["chosen"]) == og.t_move[j], (i, j)
+            assert rec[i, j]["moves"][:k].tolist() == list(og.s_moves[j][:k])
+            assert rec[i, j]["counts"][:k].tolist() == list(og.t_visits[j][:k]), (i, j)
+            assert struct.pack("<d", og.s_z[j]) == struct.pack("<d", float(rec[i, j]["z"])), (i, j)
+    assert oracle[2].n_plies == 33 and oracle[2].winner == 1                 # the early ending the schedule relies on
+    # slot 0: 33 + 33 + 70 = 136; the slots freed at ply 70 take games 6 (33 plies), 7, 8 (70): 140 plies in all
+    assert plies == 140, plies
+
+
+def test_c3_full_size_with_its_own_network(L):
+    """BASELINE config C3 end to end under test with its real evaluator: 16,384 concurrent
+    games, S = 50, the 6-block bf16 network on the hand-written kernels, 8 plies.  Size-independent properties
+    on every game (no errors, 8 samples, every ply's root visits sum to 50 - 8 = 42 [A10], the chosen move is a
+    root child with at least one visit, pi sums to 1) and, for a sample of 64 games spread over the batch, an
+    oracle replay of the played line: the legal-move list of every sample equals the rules oracle's (order
+    included) and the outcome bookkeeping agrees.  The whole run must also be reproducible bit for bit."""
+    import torch
+    from chinesechessai_amd.engine import SelfPlayEngine, TorchNetEvaluator
+    from chinesechessai_amd.neural_network import ChessNet
+    from oracle import xq_oracle as xo
+    torch.manual_seed(0)
+    net = ChessNet(num_blocks=6).eval().cuda()
+    G, S, P = 16384, 50, 8
+    seeds = np.arange(G, dtype=np.uint32)
+
+    def run():
+        ev = TorchNetEvaluator(net)
+        eng = SelfPlayEngine(G, sims=S, planes_format=ev.planes_format, max_moves=P)
+        b = eng.play(ev, seeds)
+        eng.close()
+        return b
+
+    a = run()
+    assert int(a.error.sum()) == 0 and (a.n_plies == P).all() and (a.n_samples == P).all()
+    counts = a.s_counts[:, :P].astype(np.int64)
+    assert (counts.sum(axis=2) == S - 8).all()
+    idx = np.arange(G)
+    for i in range(P):
+        n = a.s_n[:, i].astype(np.int64)
+        pos = (a.s_moves[:, i] == a.chosen[:, i][:, None]) & (np.arange(128)[None, :] < n[:, None])
+        assert (pos.sum(axis=1) == 1).all()                                   # the chosen move is one of the root's children
+        assert (counts[idx, i, pos.argmax(axis=1)] > 0).all()                 # ... and one that was visited
+    for g in np.linspace(0, G - 1, 64).astype(int):
+        env = xo.OracleEnv()
+        env.reset()
+        for i in range(P):
+            legal = env.legal_moves()
+            k = int(a.s_n[g, i])
+            assert a.s_moves[g, i, :k].tolist() == legal and int(a.chosen[g, i]) in legal, (g, i)
+            env.make_move(int(a.chosen[g, i]))
+        for _, pi, _ in a.game_data(int(g)):
+            assert abs(sum(pi.values()) - 1.0) < 1e-9
+    b = run()
+    assert np.array_equal(a.chosen, b.chosen) and np.array_equal(a.s_counts, b.s_counts)
+
+
 def test_replay_buffer_vs_reference_semantics(L):
     """the device-resident ReplayBuffer against a restatement of
     trainer.py:22-44 (deque(maxlen), push in game order, np.random.choice indices) and of the batch
