@@ -107,6 +107,8 @@ _SIGNATURES = {
     "xq_device_ok": (C.c_int, [C.c_int]),
     "xq_rules_legal_moves": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "xq_rules_query": (C.c_int, [C.c_int] + [C.c_void_p] * 7),
+    "xq_rules_threatened_pieces": (C.c_int, [C.c_int] + [C.c_void_p] * 6),
+    "xq_rules_position_key": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "xq_rules_make_move": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -54,7 +54,21 @@ def format_end_reason(code, side, count):
     return None
 
 
+class _PendingChase:
+    """Snapshot a chase_history entry is computed from when the list is first read."""
+    __slots__ = ("board", "side", "rk", "bk")
+
+    def __init__(self, board, side, rk, bk):
+        self.board, self.side, self.rk, self.bk = board, side, rk, bk
+
+
 class ChineseChess:
+    # chase_history (chess_env.py:344-345) is a dead output of the reference: nothing reads it (:674) and computing
+    # it costs the reference 51 % of its run time (SURVEY.md §8a a8).  Default: entries are computed LAZILY, the
+    # first time the list is read (one xq_rules_threatened_pieces call per pending entry); set
+    # ChineseChess.track_chase = False to keep empty placeholders instead (len() still matches).
+    track_chase = True
+
     def __init__(self):
         self.reset()
 
@@ -64,7 +78,7 @@ class ChineseChess:
         self.position_history = []
         self.no_capture_count = 0
         self.check_history = []
-        self.chase_history = []
+        self._chase = []                       # entries: list of pairs, or a pending (board, side, rk, bk) snapshot
         self.consecutive_checks = 0
         self.red_king_pos = None
         self.black_king_pos = None
@@ -148,7 +162,10 @@ class ChineseChess:
         self.consecutive_checks = int(st[0, _lib.S_CONSEC_CHECKS])
         self.position_history.append(int(key[0]))
         self.check_history.append(bool(is_check[0]))
-        self.chase_history.append([])   # dead output in the reference (chess_env.py:345,674): kept for len()
+        # chase_history entry (chess_env.py:344-345): threats of the MOVER on the position after the move, taken
+        # before the side switch — kept as a snapshot and evaluated only if somebody reads the list
+        self._chase.append(_PendingChase(b.copy(), -self.current_player, int(st[0, _lib.S_RED_KING]),
+                                         int(st[0, _lib.S_BLACK_KING])) if self.track_chase else [])
         r = float(reward[0])
         if done[0]:
             code = int(st[0, _lib.S_REASON])
@@ -156,7 +173,82 @@ class ChineseChess:
             r = _REASON_TERMINAL_INT.get(code, r)        # terminal overrides are Python ints (A16)
         return self.get_state(), r, bool(done[0])
 
+    # ---- a8: _get_threatened_pieces / chase_history ----------------------------------------
+    @staticmethod
+    def _threats(board_bytes, side, rk, bk):
+        L = _lib.lib()
+        one = lambda v: np.array([v], dtype=np.int32)
+        pairs = np.zeros((1, _lib.MAX_MOVES), dtype=np.uint16)
+        count = np.zeros(1, dtype=np.int32)
+        _lib.check(L.xq_rules_threatened_pieces(1, _lib.ptr(board_bytes), _lib.ptr(one(side)), _lib.ptr(one(rk)),
+                                                 _lib.ptr(one(bk)), _lib.ptr(pairs), _lib.ptr(count)))
+        out = []
+        for m in pairs[0, :count[0]]:
+            fr, fc, tr, tc = decode_move(m)
+            out.append(((fr, fc), (tr, tc)))
+        return out
+
+    def _get_threatened_pieces(self, player):
+        """chess_env.py:550-574: [((r, c), (tr, tc)), ...] for the pieces `player` threatens."""
+        _, rk, bk = self._scalars()
+        return self._threats(self._board_bytes(), int(player), int(rk[0]), int(bk[0]))
+
+    def _is_protected(self, r, c, player):
+        """chess_env.py:576-596.  The executed reference can never answer True: _get_piece_moves drops every move
+        onto a square held by the mover's own side (:116), so no move of `player` ends on its own piece at (r, c)
+        (pinned by tests/golden/rules_extra.json through the oracle's literal restatement)."""
+        return False
+
+    @property
+    def chase_history(self):
+        for i, e in enumerate(self._chase):
+            if isinstance(e, _PendingChase):
+                self._chase[i] = self._threats(e.board, e.side, e.rk, e.bk)
+        return self._chase
+
+    @chase_history.setter
+    def chase_history(self, value):
+        self._chase = value
+
     # ---- predicates the reference's own tests call -------------------------------------
+    def _get_position_hash(self):
+        """chess_env.py:497-504: equal values <=> equal (board, current_player); the reference's are salted Python
+        hashes, these are the 64-bit keys the HIP rules engine compares (xq_rules_position_key)."""
+        L = _lib.lib()
+        key = np.zeros(1, np.uint64)
+        player, _, _ = self._scalars()
+        _lib.check(L.xq_rules_position_key(1, _lib.ptr(self._board_bytes()), _lib.ptr(player), _lib.ptr(key)))
+        return int(key[0])
+
+    def _check_draw_by_repetition(self):
+        """chess_env.py:598-605"""
+        return self.position_history.count(self._get_position_hash()) >= 3
+
+    def _check_checkmate(self):
+        """chess_env.py:614-628"""
+        return len(self.get_legal_moves()) == 0 and self._is_in_check(self.current_player)
+
+    def _check_stalemate(self):
+        """chess_env.py:630-644"""
+        return len(self.get_legal_moves()) == 0 and not self._is_in_check(self.current_player)
+
+    def _is_move_suicide(self, from_r, from_c, to_r, to_c):
+        """chess_env.py:431-464: play the move on a copy (the king cache follows only a moving king, Appendix A5),
+        then in-check of the side to move or kings facing."""
+        probe = ChineseChess.__new__(ChineseChess)
+        probe.board = self.board.copy()
+        probe.current_player = self.current_player
+        probe.red_king_pos, probe.black_king_pos = self.red_king_pos, self.black_king_pos
+        moving = probe.board[from_r, from_c]
+        probe.board[to_r, to_c] = moving
+        probe.board[from_r, from_c] = 0
+        if moving == PIECES['R_KING']:
+            probe.red_king_pos = (to_r, to_c)
+        elif moving == PIECES['B_KING']:
+            probe.black_king_pos = (to_r, to_c)
+        red, black, facing = probe._query()
+        return (red if self.current_player == 1 else black) or facing
+
     def _query(self):
         L = _lib.lib()
         b = self._board_bytes()

@@ -915,6 +915,50 @@ __global__ __launch_bounds__(64) void k_rules_legal(int n, const int8_t *boards,
     if (lane == 0) counts[g] = cnt;
 }
 
+// a8 (chess_env.py:550-596): the (attacker, victim) pairs `side` threatens.  In the executed reference a pair is
+// every LEGAL move of `side` (generated with current_player = side: wave_movegen's contract) that captures an
+// enemy piece other than the king: _is_protected can never answer True, because _get_piece_moves drops every
+// move onto a square the mover's own side holds (:116) — pinned by tests/golden/rules_extra.json against the
+// literal oracle restatement.  Order = legal-move order; compaction by ballot prefix.
+__global__ __launch_bounds__(64) void k_rules_threats(int n, const int8_t *boards, const int32_t *side,
+                                                      const int32_t *rk, const int32_t *bk,
+                                                      uint16_t *pairs, int32_t *counts)
+{
+    __shared__ WaveLds L;
+    const int g = blockIdx.x, lane = XQ_LANE;
+    for (int s = lane; s < 96; s += 64) L.bd[s] = s < 90 ? boards[(size_t)g * 90 + s] : 0;
+    wave_sync();
+    BoardView v = load_view(L.bd);
+    const int p = side[g];
+    const int cnt = wave_movegen(L.bd, v, p, rk[g], bk[g], L.cand, L.legal, L.own_sq);
+    int base = 0;
+    for (int j0 = 0; j0 < cnt; j0 += 64) {
+        const int j = j0 + lane;
+        bool keep = false;
+        int mv = 0;
+        if (j < cnt) {
+            mv = L.legal[j];
+            const int t = L.bd[mv % 90];
+            keep = t * p < 0 && (t < 0 ? -t : t) != 1;              // an enemy piece, not the king (code 1)
+        }
+        const unsigned long long m = __ballot(keep);
+        if (keep) pairs[(size_t)g * MAXM + base + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)mv;
+        base += __popcll(m);
+    }
+    if (lane == 0) counts[g] = base;
+}
+
+// _get_position_hash (chess_env.py:497-504) as the 64-bit key the engine's repetition rule compares
+__global__ __launch_bounds__(64) void k_rules_position_key(int n, const int8_t *boards, const int32_t *player, uint64_t *keys)
+{
+    __shared__ WaveLds L;
+    const int g = blockIdx.x, lane = XQ_LANE;
+    for (int s = lane; s < 96; s += 64) L.bd[s] = s < 90 ? boards[(size_t)g * 90 + s] : 0;
+    wave_sync();
+    const uint64_t k = position_key(L.bd, player[g] == 1 ? 0 : 1);
+    if (lane == 0) keys[g] = k;
+}
+
 __global__ __launch_bounds__(64) void k_rules_query(int n, const int8_t *boards, const int32_t *player,
                                                     const int32_t *rk, const int32_t *bk,
                                                     int32_t *chk_red, int32_t *chk_black, int32_t *facing)
@@ -1045,6 +1089,42 @@ extern "C" int xq_rules_legal_moves(int n, const int8_t *boards, const int32_t *
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpy(moves, dM.p, (size_t)n * MAXM * 2, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(counts, dC.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int xq_rules_threatened_pieces(int n, const int8_t *boards, const int32_t *side, const int32_t *rk,
+                                         const int32_t *bk, uint16_t *pairs, int32_t *counts)
+{
+    if (n <= 0 || !boards || !side || !rk || !bk || !pairs || !counts) return fail(XQ_E_INVALID, "bad argument");
+    if (int rc = need_gpu()) return rc;
+    DevBuf dB, dP, dR, dK, dM, dC;
+    if (dB.alloc((size_t)n * 90) || dP.alloc((size_t)n * 4) || dR.alloc((size_t)n * 4) || dK.alloc((size_t)n * 4) ||
+        dM.alloc((size_t)n * MAXM * 2) || dC.alloc((size_t)n * 4))
+        return fail(XQ_E_HIP, "hipMalloc failed");
+    HIPCHK(hipMemcpy(dB.p, boards, (size_t)n * 90, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dP.p, side, (size_t)n * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dR.p, rk, (size_t)n * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dK.p, bk, (size_t)n * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemset(dM.p, 0, (size_t)n * MAXM * 2));
+    hipLaunchKernelGGL(k_rules_threats, dim3(n), dim3(64), 0, 0, n, dB.as<int8_t>(), dP.as<int32_t>(), dR.as<int32_t>(),
+                       dK.as<int32_t>(), dM.as<uint16_t>(), dC.as<int32_t>());
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpy(pairs, dM.p, (size_t)n * MAXM * 2, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(counts, dC.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int xq_rules_position_key(int n, const int8_t *boards, const int32_t *player, uint64_t *keys)
+{
+    if (n <= 0 || !boards || !player || !keys) return fail(XQ_E_INVALID, "bad argument");
+    if (int rc = need_gpu()) return rc;
+    DevBuf dB, dP, dK;
+    if (dB.alloc((size_t)n * 90) || dP.alloc((size_t)n * 4) || dK.alloc((size_t)n * 8)) return fail(XQ_E_HIP, "hipMalloc failed");
+    HIPCHK(hipMemcpy(dB.p, boards, (size_t)n * 90, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dP.p, player, (size_t)n * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_rules_position_key, dim3(n), dim3(64), 0, 0, n, dB.as<int8_t>(), dP.as<int32_t>(), dK.as<uint64_t>());
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpy(keys, dK.p, (size_t)n * 8, hipMemcpyDeviceToHost));
     return 0;
 }
 

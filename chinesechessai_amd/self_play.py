@@ -82,7 +82,7 @@ class MCTS:
 
 
 def _play_batch(network, num_games, temperature, num_simulations, opponent_network, seeds=None, uniforms=None,
-                inference_dtype=None, on_engine=None):
+                inference_dtype=None, partial_on_interrupt=False):
     sims = num_simulations if num_simulations else MCTS_SIMULATIONS
     ev = _evaluator_for(network, inference_dtype=inference_dtype)
     ev_b = _evaluator_for(opponent_network, inference_dtype=inference_dtype) if opponent_network is not None else None
@@ -91,14 +91,29 @@ def _play_batch(network, num_games, temperature, num_simulations, opponent_netwo
     eng = SelfPlayEngine(num_games, sims=sims, temperature=temperature, max_moves=MAX_MOVES,
                          opponent_mode=opponent_network is not None,
                          planes_format=getattr(ev, "planes_format", _lib.PLANES_NONE))
-    if on_engine is not None:
-        on_engine(eng)
     if seeds is None:
         seeds = np.random.randint(0, 2 ** 31 - 1, size=num_games).astype(np.uint32)
     try:
         return eng.play(ev, seeds, opponent_evaluator=ev_b, uniforms=uniforms)
+    except KeyboardInterrupt:
+        if not partial_on_interrupt:
+            raise
+        # self_play.py:436-452: hand back the games that had finished when Ctrl-C arrived
+        raise InterruptedWithResults(_finished_games(eng))
     finally:
         eng.close()
+
+
+def _finished_games(eng):
+    """Results of the games of a batch in flight that are already over (terminal position or move cap): the
+    z table is applied to every slot, unfinished games are filtered out."""
+    try:
+        _lib.check(eng.L.xq_engine_finalize(eng.h))
+        b = eng.read_results()
+    except Exception:
+        return []
+    over = (b.reason != 0) | (b.n_plies >= eng.max_moves)
+    return [(b.game_data(g), int(b.winner[g]), b.end_reason(g)) for g in range(b.n_games) if over[g] and b.error[g] == 0]
 
 
 def self_play_game(network, temperature=1.0, render=False, num_simulations=None, opponent_network=None):
@@ -129,13 +144,12 @@ def self_play_game(network, temperature=1.0, render=False, num_simulations=None,
 
 
 def parallel_self_play(network, num_games, temperature=1.0, num_simulations=None, num_workers=4,
-                       opponent_network=None, seeds=None):
+                       opponent_network=None, seeds=None, inference_dtype=None):
     """self_play.py:368-469.  The reference's process pool becomes G concurrent games on the GPU;
     `num_workers` is accepted and ignored.  Results come back in game order (the reference's
     order is arbitrary: imap_unordered).  Ctrl-C raises InterruptedWithResults(results) with the
-    games finished so far (none while the batch is in flight: games advance in lock-step)."""
-    try:
-        batch = _play_batch(network, num_games, temperature, num_simulations, opponent_network, seeds=seeds)
-    except KeyboardInterrupt:
-        raise InterruptedWithResults([])
+    games that had already finished (self_play.py:436-452); `inference_dtype` ("bf16" | "f32", default
+    INFERENCE_DTYPE) picks the precision a CUDA ChessNet is evaluated in."""
+    batch = _play_batch(network, num_games, temperature, num_simulations, opponent_network, seeds=seeds,
+                        inference_dtype=inference_dtype, partial_on_interrupt=True)
     return batch.results()

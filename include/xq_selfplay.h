@@ -83,6 +83,20 @@ int xq_rules_query(int n, const int8_t *boards_host, const int32_t *player_host,
                    const int32_t *red_king_host, const int32_t *black_king_host,
                    int32_t *in_check_red_host, int32_t *in_check_black_host, int32_t *facing_host);
 
+/* _get_threatened_pieces(side) (chess_env.py:550-596; called twice per make_move, :262 and :344, its second result
+ * appended to chase_history :345, which nothing reads :674): the (attacker square, victim square) pairs `side`
+ * threatens on the given boards with the given king caches, as from*90+to in the reference's scan order.
+ * pairs_host [n][XQ_MAX_MOVES], counts_host [n].  Not on the self-play path (dead output there); the host mirror
+ * fills chase_history from it on request. */
+int xq_rules_threatened_pieces(int n, const int8_t *boards_host /*[n][90]*/, const int32_t *side_host,
+                               const int32_t *red_king_host, const int32_t *black_king_host,
+                               uint16_t *pairs_host, int32_t *counts_host);
+
+/* _get_position_hash (chess_env.py:497-504) of (board, current_player) as the 64-bit key xq_rules_make_move
+ * appends to / compares with position histories: equal keys <=> equal (board, player byte).  The reference's
+ * values are salted Python hashes; only equality is part of the contract. */
+int xq_rules_position_key(int n, const int8_t *boards_host /*[n][90]*/, const int32_t *player_host, uint64_t *keys_host);
+
 /* ChineseChess.make_move (chess_env.py:253-406).
  * state_host: int32[n][XQ_STATE_WORDS], updated in place; boards_host updated in place.
  * Histories: pos_hist_host uint64[n][hist_stride] holds n_hist[i] keys previously returned in

@@ -547,6 +547,218 @@ def gen_net():
     print("net: params", int(pack["n_params"][0]), "values", pack["values_a"][:4])
 
 
+# --------------------------------------------------------------------------- round 2: rules extras
+def gen_rules_extra(seed=424242):
+    """a8 (_get_threatened_pieces / chase_history, chess_env.py:550-596,344-345), the repetition draw with an
+    injected position_history (chess_env.py:598-605: unreachable in legal play, Appendix A7) and the private
+    predicates the reference's own tests call (_check_checkmate, _check_stalemate, _is_move_suicide)."""
+    rng = random.Random(seed)
+    out = dict(chase=[], threats=[], repetition=[], predicates=[])
+    # chase_history per ply of seeded capture-heavy games + direct _get_threatened_pieces for both sides
+    for g in range(4):
+        env = chess_env.ChineseChess()
+        plies = []
+        for ply in range(60):
+            before = state_row(env)
+            legal = env.get_legal_moves()
+            if not legal:
+                break
+            caps = [m for m in legal if env.board[m[2], m[3]] != 0]
+            mv = rng.choice(caps) if (caps and rng.random() < 0.6) else rng.choice(legal)
+            _, _, done = env.make_move(mv)
+            plies.append(dict(board=before["board"].tolist(), player=before["player"], red_king=before["red_king"],
+                              black_king=before["black_king"], move=enc(mv),
+                              chase=[enc((a[0], a[1], b[0], b[1])) for a, b in env.chase_history[-1]]))
+            if ply % 7 == 3:
+                st = state_row(env)
+                out["threats"].append(dict(board=st["board"].tolist(), player=st["player"], red_king=st["red_king"],
+                                           black_king=st["black_king"],
+                                           red=[enc((a[0], a[1], b[0], b[1])) for a, b in env._get_threatened_pieces(1)],
+                                           black=[enc((a[0], a[1], b[0], b[1])) for a, b in env._get_threatened_pieces(-1)],
+                                           current_player_after=int(env.current_player)))
+            if done or env.red_king_pos is None or env.black_king_pos is None:
+                break
+        out["chase"].append(plies)
+    # repetition: inject k copies of the hash the test will compute after the move (board after, NEXT player)
+    for g in range(6):
+        env = chess_env.ChineseChess()
+        for _ in range(rng.randint(0, 12)):
+            legal = env.get_legal_moves()
+            env.make_move(rng.choice(legal))
+        legal = env.get_legal_moves()
+        quiet = [m for m in legal if env.board[m[2], m[3]] == 0] or legal
+        mv = rng.choice(quiet)
+        for k in (2, 3, 4):
+            e2 = chess_env.ChineseChess()
+            e2.board = env.board.copy(); e2.current_player = env.current_player; e2.move_count = env.move_count
+            e2.red_king_pos, e2.black_king_pos = env.red_king_pos, env.black_king_pos
+            e2.no_capture_count = env.no_capture_count
+            # the position after the move, as the repetition test will hash it (next player to move)
+            probe = chess_env.ChineseChess()
+            probe.board = env.board.copy()
+            probe.board[mv[2], mv[3]] = probe.board[mv[0], mv[1]]; probe.board[mv[0], mv[1]] = 0
+            probe.current_player = -env.current_player
+            h = probe._get_position_hash()
+            e2.position_history = [h] * k
+            before = state_row(e2)
+            _, reward, done = e2.make_move(mv)
+            code, side, cnt = reason_code(e2.end_reason)
+            out["repetition"].append(dict(board=before["board"].tolist(), player=before["player"], move_count=before["move_count"],
+                                          red_king=before["red_king"], black_king=before["black_king"],
+                                          no_capture=before["no_capture"], move=enc(mv), copies=k,
+                                          key_board=probe.board.reshape(90).astype(int).tolist(), key_player=int(probe.current_player),
+                                          reward=float(reward), done=bool(done),
+                                          winner=WINNER_NONE if e2.winner is None else int(e2.winner),
+                                          reason=code, n_hist_after=len(e2.position_history),
+                                          repetition_now=bool(e2._check_draw_by_repetition())))
+    # predicates on the edge boards and on random positions
+    boards = []
+    for name, pieces, player, rk, bk in edge_boards():
+        env = chess_env.ChineseChess()
+        env.board = np.zeros((10, 9), dtype=np.int8)
+        for (r, c), pc in pieces.items():
+            env.board[r, c] = pc
+        env.current_player = player
+        env.red_king_pos, env.black_king_pos = rk, bk
+        boards.append((name, env))
+    for g in range(12):
+        env = chess_env.ChineseChess()
+        for _ in range(rng.randint(5, 60)):
+            legal = env.get_legal_moves()
+            if not legal or env.red_king_pos is None or env.black_king_pos is None:
+                break
+            env.make_move(rng.choice(legal))
+        if env.red_king_pos is not None and env.black_king_pos is not None:
+            boards.append(("random%d" % g, env))
+    for name, env in boards:
+        st = state_row(env)
+        own = [(r, c) for r in range(10) for c in range(9) if env.board[r, c] * env.current_player > 0]
+        cand = []
+        for _ in range(30):
+            if not own:
+                break
+            fr, fc = rng.choice(own)
+            tr, tc = rng.randrange(10), rng.randrange(9)
+            if (tr, tc) != (fr, fc):
+                cand.append((fr, fc, tr, tc))
+        cand += env.get_legal_moves()[:10]
+        out["predicates"].append(dict(name=name, board=st["board"].tolist(), player=st["player"], red_king=st["red_king"],
+                                      black_king=st["black_king"], checkmate=bool(env._check_checkmate()),
+                                      stalemate=bool(env._check_stalemate()),
+                                      suicide=[[enc(m), bool(env._is_move_suicide(*m))] for m in cand]))
+    with open(os.path.join(OUT, "rules_extra.json"), "w") as f:
+        json.dump(out, f, separators=(",", ":"))
+    print("rules_extra: chase plies %d, threat probes %d (non-empty %d), repetition cases %d (draws %d), predicate boards %d (mates %d, stalemates %d)" % (
+        sum(len(p) for p in out["chase"]), len(out["threats"]), sum(1 for t in out["threats"] if t["red"] or t["black"]),
+        len(out["repetition"]), sum(1 for r in out["repetition"] if r["reason"] == 3), len(out["predicates"]),
+        sum(p["checkmate"] for p in out["predicates"]), sum(p["stalemate"] for p in out["predicates"])))
+
+
+# --------------------------------------------------------------------------- round 2: trainer-side consumers
+def gen_trainer_io(seed=99):
+    """(f-1) trainer.ReplayBuffer push / sample traces and the batch formation of trainer.py:313-321, (f-3)
+    data/best_games.pkl written by Trainer._save_best_games and the structure of Trainer.save_model's checkpoint.
+    trainer.py imports tensorboard at module level (not installed here): a stub SummaryWriter goes into
+    sys.modules first; every reference function under test runs unmodified (the Trainer methods are called on a
+    small stand-in object, so no 98 MB network is built or saved)."""
+    import pickle
+    import tempfile
+    import types
+    import torch
+    stub = types.ModuleType("torch.utils.tensorboard")
+    stub.SummaryWriter = type("SummaryWriter", (), {"__init__": lambda self, *a, **k: None})
+    sys.modules["torch.utils.tensorboard"] = stub
+    with contextlib.redirect_stdout(io.StringIO()):
+        import trainer
+        import neural_network
+    rng = np.random.RandomState(seed)
+    # synthetic games in self_play_game's tuple format
+    games = []
+    for g in range(9):
+        env = chess_env.ChineseChess()
+        gd = []
+        for ply in range(int(rng.randint(3, 14))):
+            legal = env.get_legal_moves()
+            pr = rng.dirichlet(np.ones(len(legal)))
+            gd.append((env.board.copy(), {m: np.float64(p) for m, p in zip(legal, pr)}, float(np.round(rng.uniform(-1.2, 1.5), 6))))
+            env.make_move(legal[int(rng.randint(len(legal)))])
+        games.append(gd)
+    buf = trainer.ReplayBuffer(max_size=40)                 # small capacity: the trace wraps around several times
+    net = neural_network.ChessNet.__new__(neural_network.ChessNet)      # encode_board reads no weights
+    trace = []
+    for gi, gd in enumerate(games):
+        buf.push(gd)
+        if gi % 2 == 1:
+            np.random.seed(1000 + gi)
+            bs = min(8, len(buf))
+            boards, probs, rewards = buf.sample(bs)
+            states = np.stack([net.encode_board(b, 1) for b in boards]).astype(np.float32)     # trainer.py:313-317
+            targets = torch.FloatTensor(rewards).unsqueeze(1).numpy()                            # trainer.py:319
+            trace.append(dict(after_game=gi, size=len(buf), batch=bs, seed=1000 + gi,
+                              boards=np.stack([np.asarray(b, np.int8).reshape(90) for b in boards]),
+                              rewards=np.array(rewards, np.float64), states_bits=np.packbits(states.astype(np.uint8)),
+                              targets=targets.astype(np.float32),
+                              first_probs=[[enc(m), float(p)] for m, p in list(probs[0].items())]))
+    pack = dict(n_games=np.array([len(games)]), capacity=np.array([40]))
+    for gi, gd in enumerate(games):
+        pack["g%d_boards" % gi] = np.stack([np.asarray(b, np.int8).reshape(90) for b, _, _ in gd])
+        pack["g%d_z" % gi] = np.array([z for _, _, z in gd], np.float64)
+        pack["g%d_nmoves" % gi] = np.array([len(p) for _, p, _ in gd], np.int32)
+        pack["g%d_moves" % gi] = np.concatenate([np.array([enc(m) for m in p], np.int32) for _, p, _ in gd])
+        pack["g%d_probs" % gi] = np.concatenate([np.array(list(p.values()), np.float64) for _, p, _ in gd])
+    for ti, t in enumerate(trace):
+        for k in ("boards", "rewards", "states_bits", "targets"):
+            pack["t%d_%s" % (ti, k)] = t[k]
+        pack["t%d_meta" % ti] = np.array([t["after_game"], t["size"], t["batch"], t["seed"]], np.int64)
+        pack["t%d_first_probs" % ti] = np.array(t["first_probs"], np.float64)
+    pack["n_traces"] = np.array([len(trace)])
+    np.savez_compressed(os.path.join(OUT, "trainer_io.npz"), **pack)
+
+    # best_games.pkl through the reference's own writer, from two reference games with the exact evaluator
+    cwd = os.getcwd()
+    tmp = tempfile.mkdtemp()
+    os.chdir(tmp)
+    try:
+        best = []
+        for seed_g, sims in ((2, 50), (0, 15)):
+            np.random.seed(seed_g)
+            with contextlib.redirect_stdout(io.StringIO()):
+                gd, winner, reason = self_play.self_play_game(HashNet(), temperature=1.0, num_simulations=sims)
+            best.append((gd, winner, len(gd), "训练"))
+        fake = types.SimpleNamespace(total_games=200)
+        with contextlib.redirect_stdout(io.StringIO()):
+            trainer.Trainer._save_best_games(fake, best[:1])
+            fake.total_games = 300
+            trainer.Trainer._save_best_games(fake, best[1:])
+        with open(os.path.join(tmp, "data", "best_games.pkl"), "rb") as f:
+            blob = f.read()
+        # checkpoint structure of Trainer.save_model (the file itself is ~280 MB: only its shape is recorded)
+        small = types.SimpleNamespace(total_games=1000, training_steps=7)
+        with contextlib.redirect_stdout(io.StringIO()):
+            small.network = neural_network.ChessNet()
+        small.optimizer = torch.optim.Adam(small.network.parameters(), lr=1e-3)
+        with contextlib.redirect_stdout(io.StringIO()):
+            trainer.Trainer.save_model(small)
+        files = sorted(os.listdir(os.path.join(tmp, "models")))
+        ck = torch.load(os.path.join(tmp, "models", "latest.pt"), map_location="cpu")
+        struct = dict(files=files, keys=sorted(ck.keys()), total_games=int(ck["total_games"]), training_steps=int(ck["training_steps"]),
+                      model={k: [list(v.shape), str(v.dtype)] for k, v in ck["model_state_dict"].items()},
+                      optimizer_keys=sorted(ck["optimizer_state_dict"].keys()),
+                      param_group_keys=sorted(ck["optimizer_state_dict"]["param_groups"][0].keys()),
+                      n_param_ids=len(ck["optimizer_state_dict"]["param_groups"][0]["params"]))
+    finally:
+        os.chdir(cwd)
+        import shutil
+        shutil.rmtree(tmp, ignore_errors=True)
+    with open(os.path.join(OUT, "best_games_ref.pkl"), "wb") as f:
+        f.write(blob)
+    with open(os.path.join(OUT, "checkpoint_struct.json"), "w") as f:
+        json.dump(struct, f, separators=(",", ":"))
+    games_ref = pickle.loads(blob)
+    print("trainer_io: %d games pushed, %d sample traces; best_games_ref.pkl %d bytes, %d games (%s plies); checkpoint files %s" % (
+        len(games), len(trace), len(blob), len(games_ref), [g["moves"] for g in games_ref], files))
+
+
 if __name__ == "__main__":
     what = sys.argv[1:] or ["all"]
     if "all" in what:
@@ -554,4 +766,5 @@ if __name__ == "__main__":
     for w in what:
         {"rules": gen_rules, "edge": gen_edge, "known": gen_known, "puct": gen_puct,
          "sampler": gen_sampler, "ztable": gen_ztable, "net": gen_net,
-         "search": lambda: gen_search("fast"), "search_slow": lambda: gen_search("slow")}[w]()
+         "search": lambda: gen_search("fast"), "search_slow": lambda: gen_search("slow"),
+         "rules_extra": gen_rules_extra, "trainer_io": gen_trainer_io}[w]()

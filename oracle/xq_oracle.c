@@ -292,6 +292,89 @@ int xqo_legal_moves(xqo_env *e, uint16_t *out)
     return n;
 }
 
+/* chess_env.py:90-121 for one piece: generator order, in-bounds / not-own / not-suicide filters.
+ * out[i] = from*90+to. */
+static int piece_moves(xqo_env *e, int r, int c, int piece, uint16_t *out)
+{
+    rc_t mv[20];
+    int n = 0, k = gen_piece(e, r, c, abs(piece), mv);
+    for (int i = 0; i < k; i++) {
+        int tr = mv[i].r, tc = mv[i].c;
+        if (!on_board(tr, tc)) continue;
+        int target = e->board[tr * 9 + tc];
+        if (target * e->current_player <= 0)
+            if (!xqo_is_move_suicide(e, r * 9 + c, tr * 9 + tc))
+                out[n++] = (uint16_t)((r * 9 + c) * 90 + tr * 9 + tc);
+    }
+    return n;
+}
+
+/* chess_env.py:576-596 — is the piece of `player` on (r, c) protected?  Scans player's pieces with
+ * current_player temporarily = player and looks for a move ONTO (r, c) in _get_piece_moves' output.
+ * (That output never contains a square held by the mover's own side — the :116 filter — so in the
+ * executed reference this is always False; restated literally, not simplified.) */
+int xqo_is_protected(xqo_env *e, int r, int c, int player)
+{
+    uint16_t mv[20];
+    for (int pr = 0; pr < ROWS; pr++)
+        for (int pc = 0; pc < COLS; pc++) {
+            int piece = e->board[pr * 9 + pc];
+            if (piece * player > 0) {
+                int original = e->current_player;
+                e->current_player = player;
+                int n = piece_moves(e, pr, pc, piece, mv);
+                e->current_player = original;
+                for (int i = 0; i < n; i++)
+                    if (mv[i] % 90 == r * 9 + c) return 1;
+            }
+        }
+    return 0;
+}
+
+/* chess_env.py:550-574 — (attacker square, victim square) pairs `player` threatens: every move of a piece
+ * of `player` (generated with current_player temporarily = player) that captures an enemy piece other
+ * than the king and whose victim is not protected.  out[i] = from*90+to, in scan order.  Called twice per
+ * make_move (:262, :344); only the second result is kept (chase_history, :345) and nothing reads it (:674). */
+int xqo_threatened_pieces(xqo_env *e, int player, uint16_t *out)
+{
+    uint16_t mv[20];
+    int n_out = 0;
+    for (int r = 0; r < ROWS; r++)
+        for (int c = 0; c < COLS; c++) {
+            int piece = e->board[r * 9 + c];
+            if (piece * player > 0) {
+                int original = e->current_player;
+                e->current_player = player;
+                int n = piece_moves(e, r, c, piece, mv);
+                e->current_player = original;
+                for (int i = 0; i < n; i++) {
+                    int to = mv[i] % 90, target = e->board[to];
+                    if (target * player < 0 && abs(target) != KING)
+                        if (!xqo_is_protected(e, to / 9, to % 9, -player)) {
+                            if (n_out < XQO_MAX_MOVES) out[n_out] = mv[i];
+                            n_out++;
+                        }
+                }
+            }
+        }
+    return n_out;
+}
+
+/* chess_env.py:614-628 / 630-644 */
+int xqo_check_checkmate(xqo_env *e)
+{
+    uint16_t mv[XQO_MAX_MOVES];
+    if (xqo_legal_moves(e, mv) > 0) return 0;
+    return xqo_is_in_check(e, e->current_player) ? 1 : 0;
+}
+
+int xqo_check_stalemate(xqo_env *e)
+{
+    uint16_t mv[XQO_MAX_MOVES];
+    if (xqo_legal_moves(e, mv) > 0) return 0;
+    return xqo_is_in_check(e, e->current_player) ? 0 : 1;
+}
+
 /* ------------------------------------------------------------------ make_move */
 
 /* chess_env.py:683-737 */
@@ -338,7 +421,9 @@ static void push_history(xqo_env *e, int is_check)
 }
 
 /* chess_env.py:598-605 */
-static int check_repetition(const xqo_env *e)
+int xqo_check_draw_by_repetition(const xqo_env *e);
+static int check_repetition(const xqo_env *e) { return xqo_check_draw_by_repetition(e); }
+int xqo_check_draw_by_repetition(const xqo_env *e)
 {
     uint8_t key[91];
     memcpy(key, e->board, 90);

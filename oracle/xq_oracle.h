@@ -76,6 +76,11 @@ int      xqo_are_kings_facing(const xqo_env *e);
 int      xqo_is_move_suicide(xqo_env *e, int from, int to);
 int      xqo_make_move(xqo_env *e, int move, double *reward, int *is_check);  /* returns done */
 double   xqo_position_change(const xqo_env *e, int from, int to);
+int      xqo_is_protected(xqo_env *e, int r, int c, int player);              /* chess_env.py:576-596 */
+int      xqo_threatened_pieces(xqo_env *e, int player, uint16_t *out);        /* chess_env.py:550-574; from*90+to pairs */
+int      xqo_check_checkmate(xqo_env *e);                                     /* chess_env.py:614-628 */
+int      xqo_check_stalemate(xqo_env *e);                                     /* chess_env.py:630-644 */
+int      xqo_check_draw_by_repetition(const xqo_env *e);                      /* chess_env.py:598-605 */
 
 /* ---- search ---- */
 /* returns number of root children; out_moves/out_visits in insertion (legal-move) order. */

@@ -95,6 +95,11 @@ def lib():
         L.xqo_are_kings_facing.argtypes = [C.POINTER(Env)]
         L.xqo_is_move_suicide.argtypes = [C.POINTER(Env), C.c_int, C.c_int]
         L.xqo_make_move.argtypes = [C.POINTER(Env), C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)]
+        L.xqo_is_protected.argtypes = [C.POINTER(Env), C.c_int, C.c_int, C.c_int]
+        L.xqo_threatened_pieces.argtypes = [C.POINTER(Env), C.c_int, C.POINTER(C.c_uint16)]
+        L.xqo_check_checkmate.argtypes = [C.POINTER(Env)]
+        L.xqo_check_stalemate.argtypes = [C.POINTER(Env)]
+        L.xqo_check_draw_by_repetition.argtypes = [C.POINTER(Env)]
         L.xqo_position_change.argtypes = [C.POINTER(Env), C.c_int, C.c_int]
         L.xqo_position_change.restype = C.c_double
         L.xqo_mcts_search.argtypes = [C.POINTER(Env), C.c_int, C.POINTER(Evaluator),
@@ -187,6 +192,33 @@ class OracleEnv:
         chk = C.c_int()
         done = self._L.xqo_make_move(self.p, int(move), C.byref(r), C.byref(chk))
         return r.value, bool(done), bool(chk.value)
+
+    def threatened_pieces(self, player):
+        """chess_env.py:550-574 as from*90+to pairs"""
+        out = (C.c_uint16 * MAX_MOVES)()
+        n = self._L.xqo_threatened_pieces(self.p, int(player), out)
+        return [int(out[i]) for i in range(n)]
+
+    def check_checkmate(self):
+        return bool(self._L.xqo_check_checkmate(self.p))
+
+    def check_stalemate(self):
+        return bool(self._L.xqo_check_stalemate(self.p))
+
+    def check_draw_by_repetition(self):
+        return bool(self._L.xqo_check_draw_by_repetition(self.p))
+
+    def is_move_suicide(self, move):
+        return bool(self._L.xqo_is_move_suicide(self.p, int(move) // 90, int(move) % 90))
+
+    def inject_position_history(self, board, player, copies):
+        """position_history = [hash(board + player byte)] * copies (the oracle keeps the bytes, Appendix A7)"""
+        e = self.e
+        b = np.ascontiguousarray(board, dtype=np.int8).reshape(90)
+        for i in range(copies):
+            C.memmove(e.pos_hist[i], b.ctypes.data, 90)
+            e.pos_hist[i][90] = 0 if player == 1 else 1
+        e.n_hist = copies
 
     def search(self, sims, evaluator=None):
         ev = evaluator or hashnet_evaluator()

@@ -1365,3 +1365,231 @@ def test_bench_contract_line(L, monkeypatch, capsys):
     import torch.distributed as dist
     if dist.is_initialized():
         dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------------------------------
+# round 2: a8, repetition, private predicates, reference-written trainer-side fixtures
+# ------------------------------------------------------------------------------------------------------
+def _mirror_env(p):
+    from chinesechessai_amd import ChineseChess
+    from chinesechessai_amd.chess_env import _pos
+    env = ChineseChess()
+    env.board = np.array(p["board"], np.int8).reshape(10, 9)
+    env.current_player = p["player"]
+    env.red_king_pos, env.black_king_pos = _pos(p["red_king"]), _pos(p["black_king"])
+    env.move_count = p.get("move_count", 0)
+    env.no_capture_count = p.get("no_capture", 0)
+    return env
+
+
+def test_threatened_pieces_chase_history_and_private_predicates(L, golden_dir):
+    """a8 and the private predicates (VERDICT r01 missing #3, weak #9) against tests/golden/rules_extra.json, which
+    the unmodified reference generated: xq_rules_threatened_pieces in one batch through the C ABI for every ply of
+    the chase games and both sides of the probe positions; the mirror's lazily filled chase_history along whole
+    games; _check_checkmate / _check_stalemate / _is_move_suicide / _get_position_hash on the mirror."""
+    from chinesechessai_amd import _lib
+    from chinesechessai_amd.chess_env import decode_move
+    d = json.load(open(os.path.join(golden_dir, "rules_extra.json")))
+    # (1) batch through the C ABI: positions AFTER each move (the oracle env applies the move), side = mover
+    boards, side, rk, bk, want = [], [], [], [], []
+    for game in d["chase"]:
+        env = None
+        from chinesechessai_amd import ChineseChess
+        env = ChineseChess()
+        for p in game:
+            assert env.board.reshape(90).tolist() == p["board"] and env.current_player == p["player"]
+            env.make_move(decode_move(p["move"]))
+            boards.append(env.board.reshape(90).copy()); side.append(p["player"])
+            rk.append(-1 if env.red_king_pos is None else env.red_king_pos[0] * 9 + env.red_king_pos[1])
+            bk.append(-1 if env.black_king_pos is None else env.black_king_pos[0] * 9 + env.black_king_pos[1])
+            want.append(p["chase"])
+        # the mirror's own chase_history, filled lazily on first read, == the reference's per-ply lists
+        got = [[(a[0] * 9 + a[1]) * 90 + b[0] * 9 + b[1] for a, b in e] for e in env.chase_history]
+        assert got == [p["chase"] for p in game]
+    for t in d["threats"]:
+        for s, key in ((1, "red"), (-1, "black")):
+            boards.append(np.array(t["board"], np.int8)); side.append(s); rk.append(t["red_king"]); bk.append(t["black_king"])
+            want.append(t[key])
+    n = len(side)
+    pairs = np.zeros((n, 128), np.uint16)
+    counts = np.zeros(n, np.int32)
+    _lib.check(L.xq_rules_threatened_pieces(n, _lib.ptr(np.ascontiguousarray(np.stack(boards), np.int8)),
+                                            _lib.ptr(np.array(side, np.int32)), _lib.ptr(np.array(rk, np.int32)),
+                                            _lib.ptr(np.array(bk, np.int32)), _lib.ptr(pairs), _lib.ptr(counts)))
+    for i in range(n):
+        assert pairs[i, :counts[i]].tolist() == want[i], i
+    assert sum(len(w) for w in want) > 150
+    # (2) predicates on the mirror
+    mates = 0
+    for p in d["predicates"]:
+        env = _mirror_env(p)
+        assert env._check_checkmate() == p["checkmate"] and env._check_stalemate() == p["stalemate"], p["name"]
+        for mv, expect in p["suicide"][:12]:
+            assert env._is_move_suicide(*decode_move(mv)) == expect, (p["name"], mv)
+        assert env._is_protected(0, 0, 1) is False
+        mates += p["checkmate"]
+    assert mates >= 1
+    a, b = _mirror_env(d["predicates"][0]), _mirror_env(d["predicates"][0])
+    assert a._get_position_hash() == b._get_position_hash()
+    b.current_player = -b.current_player
+    assert a._get_position_hash() != b._get_position_hash()
+
+
+def test_repetition_draw_with_injected_history(L, golden_dir):
+    """chess_env.py:598-605 has no positive case in legal play (Appendix A7: the entry a move appends carries the
+    MOVER's byte, the test hashes with the NEXT player's); the reference's cases inject k copies of the hash the
+    test will compute.  Through the mirror (position_history = k keys from _get_position_hash of the probe
+    position) and in one batch through xq_rules_make_move: draw (reason 3, reward 0 as a Python int, winner 0) for
+    k >= 3, the reference's ordinary outcome for k = 2."""
+    from chinesechessai_amd.chess_env import decode_move
+    d = json.load(open(os.path.join(golden_dir, "rules_extra.json")))
+    draws = 0
+    for r in d["repetition"]:
+        probe = _mirror_env(dict(board=r["key_board"], player=r["key_player"], red_king=r["red_king"], black_king=r["black_king"]))
+        h = probe._get_position_hash()
+        env = _mirror_env(r)
+        env.position_history = [h] * r["copies"]
+        _, reward, done = env.make_move(decode_move(r["move"]))
+        assert (float(reward), done, 2 if env.winner is None else env.winner) == (r["reward"], r["done"], r["winner"]), r
+        assert len(env.position_history) == r["n_hist_after"] and env._check_draw_by_repetition() == r["repetition_now"]
+        if r["reason"] == 3:
+            assert env.end_reason == "三次重复局面判和" and isinstance(reward, int) and reward == 0
+            draws += 1
+    assert draws == 12
+
+
+def test_replay_buffer_vs_reference_trace(L, golden_dir):
+    """(f-1) pinned to the reference class itself: tests/golden/trainer_io.npz holds the
+    games pushed into trainer.ReplayBuffer(max_size=40) and, after every second push, what its sample(bs) returned
+    under np.random.seed(s) plus the batch trainer.py:313-321 forms from it (encode_board(board, 1), FloatTensor
+    rewards) — generated by the unmodified reference.  The device ring must return the same boards, rewards,
+    move-probability keys and bit-identical state / target tensors."""
+    import torch
+    from chinesechessai_amd.chess_env import decode_move
+    from chinesechessai_amd.replay import ReplayBuffer
+    d = np.load(os.path.join(golden_dir, "trainer_io.npz"))
+    buf = ReplayBuffer(max_size=int(d["capacity"][0]))
+    traces = {int(d["t%d_meta" % t][0]): t for t in range(int(d["n_traces"][0]))}
+    for g in range(int(d["n_games"][0])):
+        boards, zs, nm = d["g%d_boards" % g], d["g%d_z" % g], d["g%d_nmoves" % g]
+        moves, probs = d["g%d_moves" % g], d["g%d_probs" % g]
+        off, game = 0, []
+        for i in range(len(zs)):
+            k = int(nm[i])
+            game.append((boards[i].reshape(10, 9), {decode_move(m): np.float64(p) for m, p in zip(moves[off:off + k], probs[off:off + k])},
+                         float(zs[i])))
+            off += k
+        buf.push(game)
+        if g in traces:
+            t = traces[g]
+            after, size, bs, seed = (int(v) for v in d["t%d_meta" % t])
+            assert len(buf) == size
+            np.random.seed(seed)
+            b, p, r = buf.sample(bs)
+            assert np.array_equal(np.stack([x.reshape(90) for x in b]), d["t%d_boards" % t])
+            assert np.array_equal(np.array(r, np.float64).view(np.int64), d["t%d_rewards" % t].view(np.int64))
+            fp = d["t%d_first_probs" % t]
+            assert [(m[0] * 9 + m[1]) * 90 + m[2] * 9 + m[3] for m in p[0].keys()] == fp[:, 0].astype(int).tolist()
+            assert np.allclose(list(p[0].values()), fp[:, 1], atol=2 ** -16)        # host pushes keep 16-bit probabilities
+            np.random.seed(seed)
+            states, targets = buf.sample_tensors(bs)
+            assert np.array_equal(np.packbits(states.cpu().numpy().astype(np.uint8)), d["t%d_states_bits" % t])
+            assert set(np.unique(states.cpu().numpy())) <= {0.0, 1.0}
+            assert np.array_equal(targets.cpu().numpy().view(np.int32), d["t%d_targets" % t].view(np.int32))
+    buf.close()
+
+
+def test_on_disk_formats_vs_reference_written_files(L, golden_dir, tmp_path):
+    """(f-3): engine output -> formats.append_best_games -> a file the reference's viewer parses exactly like the one
+    the reference's own Trainer._save_best_games wrote (tests/golden/best_games_ref.pkl: the golden seed-2 S=50 game
+    and the seed-0 S=15 game through the unmodified self_play_game + _save_best_games).  Same keys, same game_data
+    (boards, move -> float64 probability in legal-move order, z bit for bit), winner, moves, type; replayed the way
+    view_best_games.py:193-213 replays it (arg-max move of every sample through ChineseChess.make_move) the two
+    files give the same board sequence.  Checkpoint: formats.save_checkpoint has the structure Trainer.save_model
+    wrote (tests/golden/checkpoint_struct.json)."""
+    import pickle
+    import torch
+    from chinesechessai_amd import ChineseChess, formats
+    from chinesechessai_amd.engine import HashNetEvaluator
+    from chinesechessai_amd.neural_network import ChessNet
+    from chinesechessai_amd.self_play import parallel_self_play
+    ref_games = pickle.load(open(os.path.join(golden_dir, "best_games_ref.pkl"), "rb"))
+    assert [g["moves"] for g in ref_games] == [33, 70] and [g["total_games"] for g in ref_games] == [200, 300]
+    path = tmp_path / "data" / "best_games.pkl"
+    for (seed, sims), total in (((2, 50), 200), ((0, 15), 300)):
+        res = parallel_self_play(HashNetEvaluator(), 1, temperature=1.0, num_simulations=sims, seeds=np.array([seed], np.uint32))
+        formats.append_best_games(str(path), formats.best_games_from_results(res), total_games=total)
+    mine = pickle.load(open(path, "rb"))
+    assert len(mine) == len(ref_games)
+
+    def replay(game_info):                                   # view_best_games.py:193-213
+        env = ChineseChess()
+        env.reset()
+        boards = [env.board.copy()]
+        for board_state, move_probs, player in game_info["game_data"]:
+            if move_probs:
+                best = max(move_probs.items(), key=lambda x: x[1])[0]
+                env.make_move(best)
+                boards.append(env.board.copy())
+        return boards
+
+    for a, b in zip(mine, ref_games):
+        assert set(a) == set(b) == {"timestamp", "total_games", "game_data", "winner", "moves", "type"}
+        assert (a["total_games"], a["winner"], a["moves"], a["type"]) == (b["total_games"], b["winner"], b["moves"], b["type"])
+        assert type(a["timestamp"]) is type(b["timestamp"]) and len(a["game_data"]) == len(b["game_data"])
+        for (ba, pa, za), (bb, pb, zb) in zip(a["game_data"], b["game_data"]):
+            assert ba.dtype == bb.dtype and ba.shape == bb.shape and np.array_equal(ba, bb)
+            assert list(pa.keys()) == list(pb.keys())
+            assert [struct.pack("<d", float(v)) for v in pa.values()] == [struct.pack("<d", float(v)) for v in pb.values()]
+            assert type(next(iter(pa.values()))) is type(next(iter(pb.values())))
+            assert struct.pack("<d", za) == struct.pack("<d", zb) and type(za) is type(zb)
+        ra, rb = replay(a), replay(b)
+        assert len(ra) == len(rb) and all(np.array_equal(x, y) for x, y in zip(ra, rb))
+    # checkpoint structure
+    st = json.load(open(os.path.join(golden_dir, "checkpoint_struct.json")))
+    net = ChessNet()
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+    p = tmp_path / "models" / "latest.pt"
+    formats.save_checkpoint(str(p), net, opt, total_games=st["total_games"], training_steps=st["training_steps"])
+    ck = torch.load(str(p), map_location="cpu")
+    assert sorted(ck.keys()) == st["keys"] and ck["total_games"] == st["total_games"] and ck["training_steps"] == st["training_steps"]
+    assert {k: [list(v.shape), str(v.dtype)] for k, v in ck["model_state_dict"].items()} == st["model"]
+    assert sorted(ck["optimizer_state_dict"].keys()) == st["optimizer_keys"]
+    assert sorted(ck["optimizer_state_dict"]["param_groups"][0].keys()) == st["param_group_keys"]
+    assert len(ck["optimizer_state_dict"]["param_groups"][0]["params"]) == st["n_param_ids"]
+    # (the reference also writes models/model_<N>.pt when total_games % 1000 == 0: trainer.py:446-450)
+    assert st["files"] == ["latest.pt", "model_1000.pt"]
+    net2, meta = formats.load_checkpoint(str(p))
+    assert meta["total_games"] == st["total_games"] and net2.num_blocks == 4
+
+
+def test_interrupt_returns_the_games_already_finished(L, monkeypatch):
+    """self_play.py:436-452: Ctrl-C during parallel_self_play raises InterruptedWithResults carrying the games that
+    had finished.  Three S=50 games with the exact evaluator; seed 2 ends by checkmate at ply 33; the interrupt
+    arrives at ply 40: exactly that game comes back, equal to the oracle's."""
+    from chinesechessai_amd import engine as xe
+    from chinesechessai_amd.chess_env import encode_move
+    from chinesechessai_amd.engine import HashNetEvaluator
+    from chinesechessai_amd.self_play import InterruptedWithResults, parallel_self_play
+    from oracle import xq_oracle as xo
+    calls = {"n": 0}
+    real = xe.SelfPlayEngine.search
+
+    def search(self, ev):
+        calls["n"] += 1
+        if calls["n"] == 41:
+            raise KeyboardInterrupt
+        return real(self, ev)
+
+    monkeypatch.setattr(xe.SelfPlayEngine, "search", search)
+    with pytest.raises(InterruptedWithResults) as ei:
+        parallel_self_play(HashNetEvaluator(), 3, num_simulations=50, seeds=np.array([0, 2, 1], np.uint32))
+    res = ei.value.results
+    assert len(res) == 1
+    gd, winner, reason = res[0]
+    rc, og = xo.self_play_game(2, 50)
+    assert winner == og.winner == 1 and reason == "将死黑方" and len(gd) == og.n_samples == 33
+    for i, (board, pi, z) in enumerate(gd):
+        k = og.s_nmoves[i]
+        assert [encode_move(m) for m in pi.keys()] == list(og.s_moves[i][:k])
+        assert struct.pack("<d", z) == struct.pack("<d", og.s_z[i])

@@ -118,3 +118,48 @@ def test_perpetual_check_injected(golden_dir):
             assert env.e.end_reason == xo.R_PERP_CHECK and reward == -10
             # A4: the side that just moved (red) wins; the side to move is named
             assert env.e.winner == 1 and env.e.end_side == -1
+
+
+def test_round2_rules_extras_vs_reference(golden_dir):
+    """Round 2 fixtures (oracle/gen_golden.py rules_extra, generated by the unmodified reference): a8
+    _get_threatened_pieces per ply (= chase_history entries) and for both sides on probe positions, the
+    repetition draw with an injected position_history (chess_env.py:598-605), _check_checkmate /
+    _check_stalemate / _is_move_suicide on the edge boards and random positions."""
+    d = json.load(open(os.path.join(golden_dir, "rules_extra.json")))
+    n_chase = 0
+    for game in d["chase"]:
+        for p in game:
+            env = xo.OracleEnv()
+            env.set_state(p["board"], p["player"], red_king=p["red_king"], black_king=p["black_king"])
+            env.make_move(p["move"])
+            # threats_after is taken BEFORE the side switch: by the mover (chess_env.py:344-348)
+            assert env.threatened_pieces(p["player"]) == p["chase"], p
+            n_chase += len(p["chase"])
+    assert n_chase > 100
+    for t in d["threats"]:
+        env = xo.OracleEnv()
+        env.set_state(t["board"], t["player"], red_king=t["red_king"], black_king=t["black_king"])
+        assert env.threatened_pieces(1) == t["red"] and env.threatened_pieces(-1) == t["black"]
+        assert env.e.current_player == t["current_player_after"]            # the temporary side switch is undone
+    draws = 0
+    for r in d["repetition"]:
+        env = xo.OracleEnv()
+        env.set_state(r["board"], r["player"], move_count=r["move_count"], red_king=r["red_king"],
+                      black_king=r["black_king"], no_capture=r["no_capture"])
+        env.inject_position_history(r["key_board"], r["key_player"], r["copies"])
+        reward, done, _ = env.make_move(r["move"])
+        w = env.e.winner
+        assert (float(reward), bool(done), int(w), int(env.e.end_reason)) == (r["reward"], r["done"], r["winner"], r["reason"]), r
+        assert env.e.n_hist == r["n_hist_after"] and env.check_draw_by_repetition() == r["repetition_now"]
+        draws += r["reason"] == 3
+        assert (r["reason"] == 3) == (r["copies"] >= 3)
+    assert draws == 12
+    mates = stales = 0
+    for p in d["predicates"]:
+        env = xo.OracleEnv()
+        env.set_state(p["board"], p["player"], red_king=p["red_king"], black_king=p["black_king"])
+        assert env.check_checkmate() == p["checkmate"] and env.check_stalemate() == p["stalemate"], p["name"]
+        for mv, expect in p["suicide"]:
+            assert env.is_move_suicide(mv) == expect, (p["name"], mv)
+        mates += p["checkmate"]; stales += p["stalemate"]
+    assert mates >= 1 and stales >= 1
