@@ -682,8 +682,9 @@ __global__ __launch_bounds__(256, 2) void k_tower16(TowerArgs A)
 //   * activation fragments are double-buffered by K-step (all 6 of K-step k+1 are fetched during
 //     K-step k: 24 MFMAs of distance instead of 8).  The 48 registers come from the skip
 //     connection, which no longer lives in registers: the first convolution of a block re-reads
-//     the block input x from the LDS rows its epilogue is about to overwrite (same lane, same
-//     address) and starts the second convolution's accumulators at x + bias.  Every layer's bias
+//     the block input x from the LDS rows its epilogue is about to overwrite and starts the second
+//     convolution's accumulators at x + bias — through the matrix pipe: x + bias = S . X + bias with
+//     a 0/1 selector as the A operand, X as 12 ordinary fragments, bias as the C operand (exact).  Every layer's bias
 //     enters through the accumulator initialisation, so an epilogue is cvt / ReLU / store only;
 //   * stage barriers are raw s_barrier + vmcnt(0) (no LDS drain), placed behind the first pixel
 //     tile of a stage's second K-step: its 4 MFMAs consume all 4 weight fragments of the retiring
@@ -824,9 +825,9 @@ __global__ __launch_bounds__(256, 2) void k_tower16b(TowerArgs A)
         // layer loop and spills them (each reload then waits vmcnt(0) in the middle of the MFMA stream, a
         // full memory round trip that also drains the weight DMA).  An opaque copy of the row base per
         // call keeps the ~13 VALU instructions of a tap where they are written.
-        int rrow = Rrow;
-        asm volatile("" : "+v"(rrow));
-        const int slot = ((r5 + off * 32) & 0xE0) ^ q4;              // ((q ^ ((sp & 7) << 1)) << 4)
+        int rrow = Rrow, r5o = r5;
+        asm volatile("" : "+v"(rrow), "+v"(r5o));
+        const int slot = ((r5o + off * 32) & 0xE0) ^ q4;             // ((q ^ ((sp & 7) << 1)) << 4)
         const int aok = rrow + off * 256 + slot;
 #pragma unroll
         for (int nt = 0; nt < 6; nt++) {
@@ -856,6 +857,27 @@ __global__ __launch_bounds__(256, 2) void k_tower16b(TowerArgs A)
             sb[nt] = act_off + p * 256 + (qq & 1) * 8 + (((hc * 8 + (qq >> 1)) ^ ((p & 7) << 1)) << 4);
         }
         const int lbq = lb_next + (hc * 64 + 4 * qq) * 4;
+        // READ_X through the matrix pipe (default; ABL & 64 selects the VALU form it replaced: +1.3 % wall):
+        // x + bias = S . X + bias with a 0/1 selector S as the MFMA's A
+        // operand (row i of weight tile mt picks input channel (mt & 1) * 16 + i of K-step hc * 2 + (mt >> 1)), X
+        // = this wave's own 64 channels of the block input as 12 ordinary B fragments, bias as the C operand:
+        // exact (1.0 * x + zeros in fp32), 24 MFMAs + 12 ds_read_b128 instead of 144 VALU + 24 ds_read_b64 —
+        // an epilogue runs beside the partner wave's MFMA stream, where VALU issue slots are what is scarce.
+        bf16x8 xf[2][6], sel[2];
+        if constexpr (decltype(read_x)::value && (ABL & 64) == 0) {
+#pragma unroll
+            for (int k2 = 0; k2 < 2; k2++)
+#pragma unroll
+                for (int nt = 0; nt < 6; nt++) {
+                    const int p = nt * 16 + r < PIX ? nt * 16 + r : 0;
+                    xf[k2][nt] = lds_ld128(act_off + p * 256 + ((((hc * 2 + k2) * 4 + qq) ^ ((p & 7) << 1)) << 4));
+                }
+#pragma unroll
+            for (int o = 0; o < 2; o++)
+#pragma unroll
+                for (int j = 0; j < 8; j++)
+                    sel[o][j] = (qq == 2 * o + (r >> 3) && j == (r & 7)) ? (__bf16)1.0f : (__bf16)0.0f;
+        }
 #pragma unroll
         for (int mt = 0; mt < 4; mt++) {
             const f32x4 bn = lds_ldf4(lbq + mt * 64);
@@ -864,7 +886,9 @@ __global__ __launch_bounds__(256, 2) void k_tower16b(TowerArgs A)
                 const f32x4 v = acc[mt][nt];
                 const uint2 pk = make_uint2(relu_bf16x2(pack_bf16x2(v[0], v[1])), relu_bf16x2(pack_bf16x2(v[2], v[3])));
                 const int a = sb[nt] ^ (mt << 5);
-                if constexpr (decltype(read_x)::value) {
+                if constexpr (decltype(read_x)::value && (ABL & 64) == 0) {
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sel[mt & 1], xf[mt >> 1][nt], bn, 0, 0, 0);
+                } else if constexpr (decltype(read_x)::value) {
                     const u32x2 x = lds_ld64(a);                                  // same lane, same address: ordered before the store
                     acc[mt][nt] = f32x4{ bf16_lo(x.x) + bn[0], bf16_hi(x.x) + bn[1], bf16_lo(x.y) + bn[2], bf16_hi(x.y) + bn[3] };
                 } else acc[mt][nt] = bn;
@@ -1044,7 +1068,7 @@ static int launch_tower(void *stream, const void *planes, const void *w1, const 
     static bool attr_set = false;
     if (!attr_set) {
         for (const void *f : { reinterpret_cast<const void *>(&k_tower<STAMP>), reinterpret_cast<const void *>(&k_tower16<STAMP>),
-                               reinterpret_cast<const void *>(&k_tower16b<STAMP>) })
+                               reinterpret_cast<const void *>(&k_tower16b<STAMP>), reinterpret_cast<const void *>(&k_tower16b<STAMP, 64>) })
             if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) return XQ_E_HIP;
         if (STAMP)
             for (const void *f : { reinterpret_cast<const void *>(&k_tower16<true, 1>), reinterpret_cast<const void *>(&k_tower16<true, 2>),
@@ -1052,7 +1076,7 @@ static int launch_tower(void *stream, const void *planes, const void *w1, const 
                                    reinterpret_cast<const void *>(&k_tower16b<true, 1>), reinterpret_cast<const void *>(&k_tower16b<true, 2>),
                                    reinterpret_cast<const void *>(&k_tower16b<true, 4>), reinterpret_cast<const void *>(&k_tower16b<true, 8>),
                                    reinterpret_cast<const void *>(&k_tower16b<true, 16>), reinterpret_cast<const void *>(&k_tower16b<true, 32>),
-                                   reinterpret_cast<const void *>(&k_tower16b<true, 5>) })
+                                   reinterpret_cast<const void *>(&k_tower16b<true, 5>), reinterpret_cast<const void *>(&k_tower16b<true, 64>) })
                 if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) return XQ_E_HIP;
         attr_set = true;
     }
@@ -1062,8 +1086,8 @@ static int launch_tower(void *stream, const void *planes, const void *w1, const 
     const dim3 grid((n_boards + 1) / 2), blk(256);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int v = g_tower_variant;
-    if (STAMP && v >= 3) {        // ablation builds (wrong results, timing only) ride on the stamp entry point
-        if (v == 3) hipLaunchKernelGGL((k_tower16<true, 1>), grid, blk, LDS_BYTES, st, a);          // k_tower16: no refills
+    if (STAMP && v >= 4) {        // ablation builds (wrong results, timing only) ride on the stamp entry point
+        if (v == 7) hipLaunchKernelGGL((k_tower16<true, 1>), grid, blk, LDS_BYTES, st, a);          // k_tower16: no refills
         else if (v == 4) hipLaunchKernelGGL((k_tower16<true, 2>), grid, blk, LDS_BYTES, st, a);     //            no stage barriers
         else if (v == 5) hipLaunchKernelGGL((k_tower16<true, 3>), grid, blk, LDS_BYTES, st, a);     //            neither
         else if (v == 6) hipLaunchKernelGGL((k_tower16<true, 4>), grid, blk, LDS_BYTES, st, a);     //            no tap arithmetic
@@ -1074,8 +1098,10 @@ static int launch_tower(void *stream, const void *planes, const void *w1, const 
         else if (v == 16) hipLaunchKernelGGL((k_tower16b<true, 16>), grid, blk, LDS_BYTES, st, a);  // option: s_setprio 3 in epilogues
         else if (v == 17) hipLaunchKernelGGL((k_tower16b<true, 32>), grid, blk, LDS_BYTES, st, a);  // option: one filler per MFMA gap
         else if (v == 18) hipLaunchKernelGGL((k_tower16b<true, 5>), grid, blk, LDS_BYTES, st, a);   // no refills, no tap arithmetic
+        else if (v == 19) hipLaunchKernelGGL((k_tower16b<true, 64>), grid, blk, LDS_BYTES, st, a);  // comparison: skip connection on the VALU (the form before)
         else return XQ_E_INVALID;
     } else if (v == 2) hipLaunchKernelGGL(k_tower16b<STAMP>, grid, blk, LDS_BYTES, st, a);
+    else if (v == 3) hipLaunchKernelGGL((k_tower16b<STAMP, 64>), grid, blk, LDS_BYTES, st, a);
     else if (v == 1) hipLaunchKernelGGL(k_tower16<STAMP>, grid, blk, LDS_BYTES, st, a);
     else if (v == 0) hipLaunchKernelGGL(k_tower<STAMP>, grid, blk, LDS_BYTES, st, a);
     else return XQ_E_INVALID;

@@ -567,6 +567,7 @@ def test_single_launch_trunk_equals_per_layer_kernels(L):
     # (bit-identical without residual blocks).  The smallest net on a cold device comes first: that is where a
     # missing DMA wait showed in round 1.
     for variant, blocks, G in ((2, 1, 2), (2, 6, 37), (2, 2, 129), (2, 0, 5), (2, 6, 1), (2, 3, 64), (2, 20, 3), (2, 1, 1024),
+                               (3, 1, 2), (3, 6, 37), (3, 2, 129), (3, 20, 3),
                                (1, 1, 2), (1, 6, 37), (1, 2, 129), (1, 0, 5), (1, 20, 3),
                                (0, 6, 37), (0, 0, 5), (0, 2, 3)):
         L.xq_tower_set_variant(variant)

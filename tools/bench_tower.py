@@ -36,8 +36,9 @@ def timeit(fn, it=20):
 
 
 fl = 2.0 * G * 90 * (16 * 9 * 128 + 2 * blocks * 128 * 9 * 128 + 128 * 40)
-NAMES = {0: "k_tower (32x32x16)", 1: "k_tower16 (16x16x32, round 1)", 2: "k_tower16b (16x16x32, round 2)"}
-for variant in (0, 1, 2, 1, 2):
+NAMES = {0: "k_tower (32x32x16)", 1: "k_tower16 (16x16x32, round 1)", 2: "k_tower16b (16x16x32, round 2)",
+         3: "k_tower16b with the skip connection on the VALU (comparison)"}
+for variant in (1, 2, 3, 2, 3, 2):
     L.xq_tower_set_variant(variant)
     ms = timeit(lambda: L.xq_tower_nhwc_bf16(*args))
     print("%s G=%d blocks=%d: %.3f ms  %.1f TFLOP/s" % (NAMES[variant], G, blocks, ms, fl / ms / 1e9))
@@ -51,11 +52,12 @@ nwg = (G + 1) // 2
 stamps = torch.zeros(nwg * 64, dtype=torch.int64, device="cuda")
 if variant in (1, 2):
     # ablation builds (results are wrong on purpose): what the weight refills / stage barriers / tap arithmetic cost
-    abl = (((1, "stamped build"), (3, "no weight refills"), (4, "no stage barriers"), (5, "neither"),
+    abl = (((1, "stamped build"), (7, "no weight refills"), (4, "no stage barriers"), (5, "neither"),
             (6, "no per-tap address arithmetic")) if variant == 1 else
            ((2, "stamped build"), (12, "no weight refills"), (13, "no stage barriers"), (14, "no per-tap address arithmetic"),
             (15, "weight refills issued but never waited for"), (16, "OPTION s_setprio 3 in epilogues (results valid)"),
             (17, "OPTION one filler per MFMA gap (results valid)"), (18, "no refills, no tap arithmetic"),
+            (19, "comparison: skip connection on the VALU (results valid)"),
             (2, "stamped build again")))
     for v, name in abl:
         L.xq_tower_set_variant(v)

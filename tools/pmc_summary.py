@@ -14,7 +14,8 @@ import sys
 SHORT = (("k_tower", "k_tower"), ("k_conv3x3_b<16", "k_conv3x3_b<16>"), ("k_conv3x3_b<128", "k_conv3x3_b<128>"),
          ("k_heads", "k_heads"), ("k_search_round", "k_search_round"), ("k_play_move", "k_play_move"),
          ("k_end_search", "k_end_search"), ("k_new_games", "k_new_games"), ("k_pack_samples", "k_pack_samples"),
-         ("k_finalize", "k_finalize"), ("Cijk_", "policy_fc_gemm(hipBLASLt)"))
+         ("k_finalize", "k_finalize"), ("k_policy_fc", "k_policy_fc"), ("k_value_head", "k_value_head"),
+         ("k_refill", "k_refill"), ("Cijk_", "policy_fc_gemm(hipBLASLt)"))
 
 
 def short(name):
