@@ -1594,3 +1594,53 @@ def test_interrupt_returns_the_games_already_finished(L, monkeypatch):
         k = og.s_nmoves[i]
         assert [encode_move(m) for m in pi.keys()] == list(og.s_moves[i][:k])
         assert struct.pack("<d", z) == struct.pack("<d", og.s_z[i])
+
+
+def test_policy_fc_and_value_head_kernels_vs_torch(L):
+    """csrc/xq_policy.hip through the C ABI against an fp32 torch evaluation of the same bf16 operands: the policy
+    FC (both column sets: 2,304 = reachable, 8,256 = all 8,100 padded) and the value head, for row counts that
+    exercise the tile tails (1, 37, 255, 256, 300, 4,097 rows; 256-row tiles, 16-row waves), nothing written past
+    the last row, bit-identical results on repeated launches and for the same row inside batches of different
+    sizes (the accumulation order does not depend on the launch), and loud rejection of shapes the kernel does not
+    cover."""
+    import torch
+    from chinesechessai_amd import _lib
+    from chinesechessai_amd.neural_network import ChessNet, InferenceNet
+    st = torch.cuda.current_stream().cuda_stream
+    torch.manual_seed(5)
+    net = ChessNet(num_blocks=1).eval().cuda()
+    for mode, npol in (("reachable", 2304), ("all", 8256)):
+        inet = InferenceNet(net, policy_columns=mode)
+        assert inet.n_policy == npol and inet.pfw.shape == (npol, 2880)
+        ref_rows = None
+        for M in (4097, 1, 37, 255, 256, 300):
+            g = torch.Generator(device="cuda").manual_seed(1)
+            hp = (torch.rand(4097, 2880, device="cuda", generator=g) * (torch.rand(4097, 2880, device="cuda", generator=g) < 0.5)).bfloat16()[:M].contiguous()
+            flat = torch.zeros(M * 720 + 64, dtype=torch.bfloat16, device="cuda")
+            hv = flat[:M * 720].view(M, 720)
+            hv.copy_((torch.rand(4097, 720, device="cuda", generator=g))[:M].bfloat16())
+            out = torch.full((M + 1, npol), 7.0, dtype=torch.bfloat16, device="cuda")
+            val = torch.full((M + 1,), 7.0, dtype=torch.bfloat16, device="cuda")
+            for rep in range(2):
+                _lib.check(L.xq_policy_fc_bf16(st, hp.data_ptr(), inet.pfw.data_ptr(), inet.hip_pfb.data_ptr(), out.data_ptr(), M, npol, 2880))
+                _lib.check(L.xq_value_head_bf16(st, hv.data_ptr(), inet.hip_v1w.data_ptr(), inet.hip_v1b.data_ptr(),
+                                                inet.hip_v2w.data_ptr(), inet.hip_v2b.data_ptr(), val.data_ptr(), M))
+                torch.cuda.synchronize()
+                if rep == 0:
+                    first = (out.clone(), val.clone())
+            assert torch.equal(out, first[0]) and torch.equal(val, first[1])                       # run to run
+            assert (out[M] == 7.0).all() and val[M] == 7.0                                        # nothing past the last row
+            ref = hp.float() @ inet.pfw.float().t() + inet.hip_pfb
+            assert (out[:M].float() - ref).abs().max().item() <= 2 ** -8 * max(1.0, ref.abs().max().item())
+            h1 = torch.relu(hv.float() @ inet.hip_v1w.float()[:, :720].t() + inet.hip_v1b)
+            vref = torch.tanh(h1 @ inet.hip_v2w + inet.hip_v2b)
+            assert (val[:M].float() - vref).abs().max().item() <= 2 ** -7
+            if M == 4097:
+                ref_rows = (out[:300].clone(), val[:300].clone())
+            else:                                                                                 # same rows, other batch size
+                k = min(M, 300)
+                assert torch.equal(out[:k], ref_rows[0][:k]) and torch.equal(val[:k], ref_rows[1][:k]), (mode, M)
+        assert L.xq_policy_fc_bf16(st, hp.data_ptr(), inet.pfw.data_ptr(), inet.hip_pfb.data_ptr(), out.data_ptr(), 4, npol - 1, 2880) == -1
+        assert L.xq_policy_fc_bf16(st, hp.data_ptr(), inet.pfw.data_ptr(), inet.hip_pfb.data_ptr(), out.data_ptr(), 4, npol, 2870) == -1
+        assert L.xq_policy_fc_bf16(st, None, inet.pfw.data_ptr(), inet.hip_pfb.data_ptr(), out.data_ptr(), 4, npol, 2880) == -1
+    assert L.xq_value_head_bf16(st, None, None, None, None, None, None, 4) == -1
