@@ -177,6 +177,10 @@ def main():
                     help="'reachable' (default): the policy FC computes the 2,294 of 8,100 columns a legal move can index - the "
                          "search gathers legal-move logits only (neural_network.py:148-169), the rest are dead outputs; "
                          "'all': the reference's full 8,100-column head")
+    ap.add_argument("--root-eval-carry", action="store_true",
+                    help="opt-in, result-identical (reported beside the headline, never instead of it): the played child's network "
+                         "evaluation is carried over as the next root's instead of being computed a second time, so round 0 of "
+                         "every ply after the first needs no tree kernel and no network forward (6 forwards per ply instead of 7)")
     ap.add_argument("--tree-reuse", action="store_true", help="extension: keep the played move's subtree (no reference oracle)")
     ap.add_argument("--virtual-loss", action="store_true", help="extension: up to 8 distinct leaves per game and round (8x the network rows)")
     ap.add_argument("--fused-tower", type=int, default=1, help="1 = whole trunk in one launch (k_tower), 0 = one launch per convolution")
@@ -335,6 +339,8 @@ def run_rank(args):
         torch.cuda.synchronize()
 
     eng = SelfPlayEngine(G, sims=S, planes_format=ev.planes_format, device=dev, stream=stream)
+    if args.root_eval_carry:
+        eng.set_root_eval_carry(True)
     if args.tree_reuse:
         eng.set_tree_reuse(True)
     if args.virtual_loss:
@@ -402,6 +408,10 @@ def run_rank(args):
         if args.root_noise or args.temp_cutoff:
             extras.append(", Dirichlet root noise %s, temperature 1 -> 0 at ply %d (extensions, no reference oracle)"
                           % (args.root_noise, args.temp_cutoff))
+        if args.root_eval_carry:
+            extras.append("; ROOT EVALUATION CARRY-OVER (opt-in, result-identical: the new root's priors come from the evaluation "
+                          "the played child got during the previous ply's search, %d network forwards in this run instead of %d; "
+                          "reported beside the headline, not instead of it)" % (n_fw, args.steps * 70 * eng.rounds))
         if args.tree_reuse:
             extras.append(", tree reuse (extension)")
         if args.virtual_loss:
@@ -410,7 +420,7 @@ def run_rank(args):
             extras.append("; REFILL mode: %d games per GPU and step through the %d slots, a finished game's slot restarted at "
                           "once (steady state; reported beside the headline lock-step number, not instead of it)" % (args.refill, G))
         workload = "%s%d concurrent games/GPU, %d sims, %d-block ResNet %s, random-init weights, start positions, seeds base+g%s" % (
-            "BASELINE configs[2]: " if (G, S, args.blocks) == (16384, 50, 6) and not args.refill else "",
+            "BASELINE configs[2]: " if (G, S, args.blocks) == (16384, 50, 6) and not args.refill and not args.root_eval_carry else "",
             G, S, args.blocks, args.dtype, "".join(extras))
         out = {
             "metric": "self-play games/sec @ 50 MCTS sims" if S == 50 else "self-play games/sec @ %d MCTS sims" % S,

@@ -141,6 +141,8 @@ _SIGNATURES = {
     "xq_engine_read_games": (C.c_int, [C.c_void_p] * 8),
     "xq_engine_read_samples": (C.c_int, [C.c_void_p] * 9),
     "xq_engine_pack_samples": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "xq_engine_set_root_eval_carry": (C.c_int, [C.c_void_p, C.c_int]),
+    "xq_engine_roots_not_ready": (C.c_int, [C.c_void_p, C.c_void_p]),
     "xq_engine_refill_begin": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "xq_engine_refill_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "xq_engine_refill_read_games": (C.c_int, [C.c_void_p] * 8),

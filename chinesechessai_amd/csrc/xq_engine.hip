@@ -87,6 +87,8 @@ struct Eng {
     // tree root per game: always node 0 (fresh tree every ply, self_play.py:98) unless the opt-in
     // tree reuse keeps the played child's subtree (extension)
     uint16_t *root_node; int tree_reuse;
+    // opt-in: carry the played child's network evaluation over as the next root's (xq_engine_set_root_eval_carry)
+    int eval_carry; uint8_t *root_ready; int32_t *roots_not_ready;
     // virtual loss (opt-in extension): K = leaf_slots pending leaves per game and round instead of one
     // (every leaf_* / priors / values array and the evaluator's rows are indexed by slot = g * K + k);
     // nVl counts the pending visits through a node and is folded into PUCT as N + vl, W - vl
@@ -438,7 +440,10 @@ __device__ void new_game(const Eng &E, int g, WaveLds &L)
     store_gs(E.gs + g, gs);
     const int K = E.leaf_slots;
     for (int k = lane; k < K; k += 64) { E.leaf_node[(size_t)g * K + k] = LEAF_NONE; E.leaf_mult[(size_t)g * K + k] = 0; }
-    if (lane == 0) E.root_node[g] = 0;
+    if (lane == 0) {
+        E.root_node[g] = 0;
+        if (E.eval_carry) { E.root_ready[g] = 0; atomicAdd(E.roots_not_ready, 1); }
+    }
 }
 
 __global__ __launch_bounds__(64) void k_new_games(Eng E)
@@ -503,6 +508,7 @@ __global__ __launch_bounds__(64, OCC) void k_search_round(Eng E, int round, int 
     const int K = VL ? E.leaf_slots : 1;             // pending-leaf slots of this game: g * K + k
     int root = 0;
 
+    if (round == 0 && E.eval_carry && E.root_ready[g]) return;     // k_play_move already built this ply's expanded root
     if (round == 0) {
         // tree reuse (opt-in): k_play_move left the played child as the root when it had been
         // expanded; keep its subtree while a whole ply's expansions still fit the arena
@@ -781,6 +787,34 @@ __global__ __launch_bounds__(64) void k_play_move(Eng E)
     // self_play.py:203,205-208,255-256: stop on done, on MAX_MOVES, or when nothing is legal
     gs.done = (mr.done || gs.n_plies >= E.max_moves || mr.n_legal == 0) ? 1 : 0;
     store_gs(E.gs + g, gs);
+    if (E.eval_carry && !gs.done) {
+        // The reference rebuilds its tree every ply and so evaluates the new root again, although the position
+        // was evaluated during this ply's search: the played child has visits, hence was expanded from a network
+        // row for exactly this (board, player).  The evaluator is deterministic and row-independent, so that
+        // second evaluation returns the same priors bit for bit: take them from the child's expansion and leave
+        // the tree as round 0 would (root.visit_count = first batch size, children unvisited, self_play.py:103-148).
+        const int c = first + pick, n = T.nc[c], fc = T.first[c];
+        const int j0 = lane, j1 = lane + 64;
+        const uint16_t m0 = j0 < n ? T.mv[fc + j0] : (uint16_t)0, m1 = j1 < n ? T.mv[fc + j1] : (uint16_t)0;
+        const float p0 = j0 < n ? T.P[fc + j0] : 0.f, p1 = j1 < n ? T.P[fc + j1] : 0.f;
+        // (the child's move list is the legal-move list the leaf's make_move produced: it must equal this one)
+        const bool same = (j0 >= n || m0 == L.legal[j0]) && (j1 >= n || m1 == L.legal[j1]);
+        const bool ok = n != 0 && n == mr.n_legal && __all(same);
+        wave_sync();
+        if (ok) {
+            if (j0 < n) { const int x = 1 + j0; T.N[x] = 0; T.W[x] = 0.0; T.P[x] = p0; T.mv[x] = m0; T.first[x] = 0; T.nc[x] = 0; T.fl[x] = 0; }
+            if (j1 < n) { const int x = 1 + j1; T.N[x] = 0; T.W[x] = 0.0; T.P[x] = p1; T.mv[x] = m1; T.first[x] = 0; T.nc[x] = 0; T.fl[x] = 0; }
+            if (lane == 0) {
+                const int b0 = E.sims < E.leaf_batch ? E.sims : E.leaf_batch;
+                T.N[0] = (uint32_t)b0; T.W[0] = 0.0; T.P[0] = 0.f; T.mv[0] = 0; T.first[0] = 1; T.nc[0] = (uint8_t)n; T.fl[0] = 0;
+                E.n_nodes[g] = (uint32_t)(1 + n); E.root_node[g] = 0;
+            }
+        }
+        if (lane == 0) {
+            E.root_ready[g] = ok ? 1 : 0;
+            if (!ok) atomicAdd(E.roots_not_ready, 1);
+        }
+    }
 }
 
 // self_play.py:259-310
@@ -1381,6 +1415,7 @@ extern "C" int xq_engine_new_games(xq_engine *e, const uint32_t *seeds)
     mt_uniforms_many(seeds, G, u.data());
     HIPCHK(hipMemcpyAsync(e->E.uniforms, u.data(), u.size() * 8, hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));          // u is a local: copy must finish
+    if (e->E.eval_carry) HIPCHK(hipMemsetAsync(e->E.roots_not_ready, 0, 4, e->stream));
     hipLaunchKernelGGL(k_new_games, dim3(e->E.G), dim3(64), 0, e->stream, e->E);
     HIPCHK(hipGetLastError());
     return 0;
@@ -1398,6 +1433,7 @@ extern "C" int xq_engine_set_root_noise(xq_engine *e, double alpha, double epsil
 {
     if (!e) return fail(XQ_E_INVALID, "null engine");
     if (epsilon < 0.0 || epsilon > 1.0 || (epsilon > 0.0 && alpha <= 0.0)) return fail(XQ_E_INVALID, "bad alpha / epsilon");
+    if (epsilon > 0.0 && e->E.eval_carry) return fail(XQ_E_INVALID, "root noise cannot be combined with root evaluation carry-over");
     e->E.noise_alpha = alpha; e->E.noise_eps = epsilon; e->E.noise_seed = seed;
     return 0;
 }
@@ -1445,6 +1481,7 @@ extern "C" int xq_engine_set_tree_reuse(xq_engine *e, int enable)
     if (!e) return fail(XQ_E_INVALID, "null engine");
     HIPCHK(hipSetDevice(e->cfg.device));
     Eng &E = e->E;
+    if (enable && E.eval_carry) return fail(XQ_E_INVALID, "tree reuse cannot be combined with root evaluation carry-over");
     E.tree_reuse = enable ? 1 : 0;
     if (int rc = grow_nodes(e)) return rc;
     HIPCHK(hipMemsetAsync(E.root_node, 0, (size_t)E.G * 2, e->stream));
@@ -1477,6 +1514,7 @@ extern "C" int xq_engine_set_virtual_loss(xq_engine *e, int enable)
         E.leaf_slots = K;
         HIPCHK(hipMemsetAsync(E.leaf_node, 0xff, S * 2, e->stream));        // LEAF_NONE
     }
+    if (enable && E.eval_carry) return fail(XQ_E_INVALID, "virtual loss cannot be combined with root evaluation carry-over");
     E.vloss = enable ? 1 : 0;
     return grow_nodes(e);
 }
@@ -1642,9 +1680,45 @@ extern "C" int xq_engine_play_move(xq_engine *e)
         ev = next_events(e->ev_play, e->ev_play_used);
         if (ev) HIPCHK(hipEventRecord(ev->first, e->stream));
     }
+    if (e->E.eval_carry) HIPCHK(hipMemsetAsync(e->E.roots_not_ready, 0, 4, e->stream));
     hipLaunchKernelGGL(k_play_move, dim3(e->E.G), dim3(64), 0, e->stream, e->E);
     HIPCHK(hipGetLastError());
     if (ev) HIPCHK(hipEventRecord(ev->second, e->stream));
+    return 0;
+}
+
+// Opt-in, result-identical work elimination (default off; no counterpart in the reference, which rebuilds its
+// tree every ply, self_play.py:98): the network evaluation of the position a game moves into is carried over
+// from this ply's search to the next ply's root instead of being computed a second time.  The played child has
+// visits, so it was expanded from a network row for exactly that (board, player); the evaluator is
+// deterministic and row-independent, so the reference's fresh evaluation of the new root would return the same
+// priors bit for bit.  xq_engine_play_move then leaves every continuing game with the tree round 0 would have
+// produced (root.visit_count = first batch, children unvisited); the caller skips round 0 — tree kernel and
+// network forward — whenever xq_engine_roots_not_ready reports 0 (it reports the games that still need it:
+// fresh games, and any game whose played child was not expanded).  Not combinable with tree reuse, virtual loss
+// or root noise.  Call before xq_engine_new_games.
+extern "C" int xq_engine_set_root_eval_carry(xq_engine *e, int enable)
+{
+    if (!e) return fail(XQ_E_INVALID, "null engine");
+    Eng &E = e->E;
+    if (enable && (E.tree_reuse || E.vloss || E.noise_eps > 0.0 || E.opponent_mode))
+        return fail(XQ_E_INVALID, "root evaluation carry-over cannot be combined with tree reuse, virtual loss, root noise or "
+                                  "opponent mode (the carried priors are the mover's network's)");
+    HIPCHK(hipSetDevice(e->cfg.device));
+    if (enable && !E.root_ready) {
+        if (dalloc(e, E.root_ready, (size_t)E.G) || dalloc(e, E.roots_not_ready, (size_t)1)) return fail(XQ_E_HIP, "hipMalloc failed");
+    }
+    E.eval_carry = enable ? 1 : 0;
+    return 0;
+}
+
+extern "C" int xq_engine_roots_not_ready(xq_engine *e, int32_t *n)
+{
+    if (!e || !n) return fail(XQ_E_INVALID, "null argument");
+    if (!e->E.eval_carry) { *n = e->E.G; return 0; }
+    HIPCHK(hipSetDevice(e->cfg.device));
+    HIPCHK(hipMemcpyAsync(n, e->E.roots_not_ready, 4, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
     return 0;
 }
 
@@ -1681,6 +1755,7 @@ extern "C" int xq_engine_refill_begin(xq_engine *e, const uint32_t *seeds, int t
     HIPCHK(hipMemcpyAsync(e->next_game, &next, 4, hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipMemsetAsync(e->out_gs, 0, T * sizeof(GameS), e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));          // locals: the copies must finish
+    if (e->E.eval_carry) HIPCHK(hipMemsetAsync(e->E.roots_not_ready, 0, 4, e->stream));
     hipLaunchKernelGGL(k_new_games, dim3(e->E.G), dim3(64), 0, e->stream, e->E);
     HIPCHK(hipGetLastError());
     return 0;

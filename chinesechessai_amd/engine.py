@@ -222,11 +222,26 @@ class SelfPlayEngine:
         states = np.ascontiguousarray(states, dtype=np.int32).reshape(self.n_games, _lib.STATE_WORDS)
         _lib.check(self.L.xq_engine_set_roots(self.h, _lib.ptr(boards), _lib.ptr(states)))
 
-    def search(self, evaluator):
-        """One MCTS.search for every game (self_play.py:89-154); root visits are final after it."""
+    def set_root_eval_carry(self, enable=True):
+        """Opt-in, result-identical: the played child's network evaluation becomes the next root's instead of being
+        computed a second time (the reference rebuilds its tree every ply, self_play.py:98); round 0 of a ply — tree
+        kernel and network forward — is then skipped whenever no game needs it.  Call before new games start."""
+        _lib.check(self.L.xq_engine_set_root_eval_carry(self.h, 1 if enable else 0))
+        self.root_eval_carry = bool(enable)
+
+    def roots_not_ready(self):
+        n = np.zeros(1, np.int32)
+        _lib.check(self.L.xq_engine_roots_not_ready(self.h, _lib.ptr(n)))
+        return int(n[0])
+
+    def search(self, evaluator, skip_round0=False):
+        """One MCTS.search for every game (self_play.py:89-154); root visits are final after it.
+        skip_round0: every root already holds its expansion (set_root_eval_carry + roots_not_ready() == 0)."""
         kind, a, v = _lib.EVAL_PRIORS, None, None
+        if skip_round0:
+            a, v = self.priors_ptr, self.values_ptr          # nothing is pending: round 1 has nothing to consume
         pp = evaluator.planes_ptr()
-        for r in range(self.rounds):
+        for r in range(1 if skip_round0 else 0, self.rounds):
             _lib.check(self.L.xq_engine_search_round(self.h, r, kind, a, v, pp))
             kind, a, v = evaluator.evaluate(self)
         _lib.check(self.L.xq_engine_end_search(self.h, kind, a, v))
@@ -300,6 +315,10 @@ class SelfPlayEngine:
             self.set_uniforms(uniforms)
         self.ply_temperature = []
         cur_t = None
+        carry = getattr(self, "root_eval_carry", False)
+        if carry and opponent_evaluator is not None:
+            raise _lib.XqError("root evaluation carry-over needs one network for both sides (the carried priors are the mover's network's)")
+        skip0 = False
         for ply in range(min(self.max_moves, _lib.MAX_PLIES)):
             t = self.temperature if temperature_schedule is None else float(temperature_schedule(ply))
             if temperature_schedule is not None and t != cur_t:
@@ -307,8 +326,9 @@ class SelfPlayEngine:
                 cur_t = t
             self.ply_temperature.append(t)
             ev = evaluator if (ply % 2 == 0 or opponent_evaluator is None) else opponent_evaluator   # self_play.py:211
-            self.search(ev)
+            self.search(ev, skip_round0=skip0)
             _lib.check(self.L.xq_engine_play_move(self.h))
+            skip0 = carry and self.roots_not_ready() == 0
             if check_every and ply % check_every == check_every - 1 and self.active_games() == 0:
                 break
         _lib.check(self.L.xq_engine_finalize(self.h))
@@ -326,11 +346,14 @@ class SelfPlayEngine:
         active = np.zeros(1, np.int32)
         plies = 0
         cap = max_plies or (total // self.n_games + 2) * _lib.MAX_PLIES + 8
+        carry = getattr(self, "root_eval_carry", False)
+        skip0 = False
         while plies < cap:
-            self.search(evaluator)
+            self.search(evaluator, skip_round0=skip0)
             _lib.check(self.L.xq_engine_play_move(self.h))
             poll = plies % check_every == check_every - 1
             _lib.check(self.L.xq_engine_refill_step(self.h, C.c_void_p(records_ptr), _lib.ptr(active) if poll else None))
+            skip0 = carry and self.roots_not_ready() == 0        # (after the refill: restarted slots need their round 0)
             plies += 1
             if poll and int(active[0]) == 0:
                 break

@@ -248,6 +248,16 @@ typedef struct {
 } xq_sample_record;
 int  xq_engine_pack_samples(xq_engine *e, void *records_dev /* xq_sample_record[G][70] */);
 
+/* Opt-in, result-identical work elimination (default off; the reference has no counterpart: it rebuilds its tree
+ * every ply, self_play.py:98, and so evaluates every new root a second time).  With it on, xq_engine_play_move
+ * carries the played child's network evaluation over as the next root's and leaves the tree as round 0 would
+ * (root.visit_count = first batch size, children unvisited); the caller may then skip round 0 — tree kernel and
+ * network forward — of a ply whenever xq_engine_roots_not_ready reports 0 games needing it (fresh games always
+ * need it).  Games, visit counts, pi and z are bit-identical to the default path with a deterministic evaluator.
+ * Not combinable with tree reuse, virtual loss or root noise; call before xq_engine_new_games. */
+int  xq_engine_set_root_eval_carry(xq_engine *e, int enable);
+int  xq_engine_roots_not_ready(xq_engine *e, int32_t *n_host);
+
 /* ---- refill: `total` games through the engine's G concurrent slots, a finished game's slot being restarted
  * on the next unplayed game at once — what the reference's pool does by construction (imap_unordered hands a
  * worker its next game as soon as one ends, self_play.py:404-408).  A game's result depends only on

@@ -1644,3 +1644,83 @@ def test_policy_fc_and_value_head_kernels_vs_torch(L):
         assert L.xq_policy_fc_bf16(st, hp.data_ptr(), inet.pfw.data_ptr(), inet.hip_pfb.data_ptr(), out.data_ptr(), 4, npol, 2870) == -1
         assert L.xq_policy_fc_bf16(st, None, inet.pfw.data_ptr(), inet.hip_pfb.data_ptr(), out.data_ptr(), 4, npol, 2880) == -1
     assert L.xq_value_head_bf16(st, None, None, None, None, None, None, 4) == -1
+
+
+def test_root_eval_carry_is_result_identical(L):
+    """Opt-in xq_engine_set_root_eval_carry: the played child's network evaluation is carried over as the next root's
+    instead of being computed a second time (the reference rebuilds its tree every ply and evaluates the root
+    again, self_play.py:98).  Moves, root visit counts, z and outcomes must be bit-identical to the default path —
+    with the exact evaluator against the oracle as well (seed 2 ends by checkmate at ply 33), with the bf16 network
+    on the hand-written kernels, and under refill — while the evaluator is called (rounds - 1) times per ply after
+    the first; and the option must refuse the combinations it cannot serve."""
+    import torch
+    from chinesechessai_amd import _lib, distributed as xd
+    from chinesechessai_amd.engine import HashNetEvaluator, SelfPlayEngine, TorchNetEvaluator
+    from chinesechessai_amd.neural_network import ChessNet
+    from oracle import xq_oracle as xo
+
+    class Counting:
+        def __init__(self, ev):
+            self.ev, self.calls, self.planes_format = ev, 0, ev.planes_format
+
+        def bind(self, e): self.ev.bind(e)
+        def planes_ptr(self): return self.ev.planes_ptr()
+
+        def evaluate(self, e):
+            self.calls += 1
+            return self.ev.evaluate(e)
+
+    def play(make_ev, G, S, carry, max_moves=70, seeds=None):
+        ev = Counting(make_ev())
+        eng = SelfPlayEngine(G, sims=S, planes_format=ev.planes_format, max_moves=max_moves)
+        if carry:
+            eng.set_root_eval_carry(True)
+        b = eng.play(ev, np.arange(G, dtype=np.uint32) if seeds is None else seeds)
+        eng.close()
+        return b, ev.calls
+
+    # exact evaluator, whole games, vs the default path and vs the oracle
+    seeds = np.array([2, 0, 1, 3, 7, 11], np.uint32)
+    a, calls_a = play(HashNetEvaluator, 6, 50, False, seeds=seeds)
+    b, calls_b = play(HashNetEvaluator, 6, 50, True, seeds=seeds)
+    for k in ("chosen", "s_counts", "s_moves", "s_n", "winner", "reason", "n_plies", "n_samples", "error"):
+        assert np.array_equal(getattr(a, k), getattr(b, k)), k
+    assert np.array_equal(a.s_z.view(np.int64), b.s_z.view(np.int64))
+    rc, og = xo.self_play_game(2, 50)
+    assert b.n_plies[0] == og.n_plies == 33 and list(og.t_move[:33]) == b.chosen[0, :33].tolist()
+    plies = int(a.n_plies.max())
+    assert calls_a == 7 * plies and calls_b == 6 * plies + 1, (calls_a, calls_b, plies)      # round 0 only at ply 0
+    # the bf16 network
+    torch.manual_seed(1)
+    net = ChessNet(num_blocks=2).eval().cuda()
+    a, ca = play(lambda: TorchNetEvaluator(net), 96, 24, False, max_moves=14)
+    b, cb = play(lambda: TorchNetEvaluator(net), 96, 24, True, max_moves=14)
+    assert np.array_equal(a.chosen, b.chosen) and np.array_equal(a.s_counts, b.s_counts)
+    assert np.array_equal(a.s_z.view(np.int64), b.s_z.view(np.int64)) and int(b.error.sum()) == 0
+    assert ca == 3 * 14 and cb == 2 * 14 + 1
+    # refill: restarted slots get their round 0, everybody else skips it
+    rs = np.array([2, 0, 1, 3, 2, 5, 2, 6, 7, 2], dtype=np.uint32)
+    outs = []
+    for carry in (False, True):
+        eng = SelfPlayEngine(4, sims=50)
+        if carry:
+            eng.set_root_eval_carry(True)
+        rec_t = torch.zeros(len(rs) * 70 * xd.RECORD_BYTES, dtype=torch.uint8, device="cuda")
+        ev = Counting(HashNetEvaluator())
+        out, n_plies = eng.play_refill(ev, rs, rec_t.data_ptr(), check_every=1)
+        outs.append((out, rec_t.cpu().numpy().copy(), n_plies, ev.calls))
+        eng.close()
+    assert outs[0][2] == outs[1][2] == 140 and np.array_equal(outs[0][1], outs[1][1])
+    assert all(np.array_equal(outs[0][0][k], outs[1][0][k]) for k in outs[0][0])
+    assert outs[1][3] < outs[0][3] and outs[0][3] == 7 * 140
+    # combinations the option does not serve
+    eng = SelfPlayEngine(2, sims=16)
+    eng.set_root_eval_carry(True)
+    for fn in (lambda: eng.set_tree_reuse(True), lambda: eng.set_virtual_loss(True), lambda: eng.set_root_noise(0.3, 0.25)):
+        with pytest.raises(_lib.XqError):
+            fn()
+    eng.close()
+    eng = SelfPlayEngine(2, sims=16, opponent_mode=True)
+    with pytest.raises(_lib.XqError):
+        eng.set_root_eval_carry(True)
+    eng.close()
