@@ -1724,3 +1724,35 @@ def test_root_eval_carry_is_result_identical(L):
     with pytest.raises(_lib.XqError):
         eng.set_root_eval_carry(True)
     eng.close()
+
+
+def test_results_do_not_depend_on_the_sharding(L):
+    """(e): games are sharded across ranks by contiguous index blocks with seeds base + g (distributed.game_seeds).  A
+    game's result must not depend on which shard it lands in, on the shard's size or on its row in the evaluator
+    batch — with the real bf16 network, not only with the exact evaluator: 96 games as one batch == the same games
+    as shards of 64 + 32 and of 1 + 95, bit for bit (round 1 could not assert this: its library GEMM was not
+    reproducible)."""
+    import torch
+    from chinesechessai_amd import distributed as xd
+    from chinesechessai_amd.engine import SelfPlayEngine, TorchNetEvaluator
+    from chinesechessai_amd.neural_network import ChessNet
+    torch.manual_seed(2)
+    net = ChessNet(num_blocks=2).eval().cuda()
+    N, S, P = 96, 24, 10
+
+    def play(seeds):
+        ev = TorchNetEvaluator(net)
+        eng = SelfPlayEngine(len(seeds), sims=S, planes_format=ev.planes_format, max_moves=P)
+        b = eng.play(ev, seeds)
+        eng.close()
+        return b
+
+    whole = play(xd.game_seeds(500, N, 0, 1))
+    assert int(whole.error.sum()) == 0
+    for cuts in ((0, 64, 96), (0, 1, 96)):
+        for lo, hi in zip(cuts[:-1], cuts[1:]):
+            part = play((np.uint64(500) + np.arange(lo, hi, dtype=np.uint64)).astype(np.uint32))
+            assert np.array_equal(part.chosen, whole.chosen[lo:hi]) and np.array_equal(part.s_counts, whole.s_counts[lo:hi])
+            assert np.array_equal(part.s_z.view(np.int64), whole.s_z[lo:hi].view(np.int64))
+    # and the shard arithmetic itself: the seeds of a 3-rank run are those of the single-rank run
+    assert np.array_equal(np.concatenate([xd.game_seeds(500, N, r, 3) for r in range(3)]), xd.game_seeds(500, N, 0, 1))
