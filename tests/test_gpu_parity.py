@@ -1576,11 +1576,11 @@ def test_interrupt_returns_the_games_already_finished(L, monkeypatch):
     calls = {"n": 0}
     real = xe.SelfPlayEngine.search
 
-    def search(self, ev):
+    def search(self, ev, **kw):
         calls["n"] += 1
         if calls["n"] == 41:
             raise KeyboardInterrupt
-        return real(self, ev)
+        return real(self, ev, **kw)
 
     monkeypatch.setattr(xe.SelfPlayEngine, "search", search)
     with pytest.raises(InterruptedWithResults) as ei:
