@@ -184,6 +184,7 @@ def main():
     ap.add_argument("--tree-reuse", action="store_true", help="extension: keep the played move's subtree (no reference oracle)")
     ap.add_argument("--virtual-loss", action="store_true", help="extension: up to 8 distinct leaves per game and round (8x the network rows)")
     ap.add_argument("--fused-tower", type=int, default=1, help="1 = whole trunk in one launch (k_tower), 0 = one launch per convolution")
+    ap.add_argument("--tower-variant", type=int, default=-1, help="diagnostic: trunk kernel build (8 = default, 2 = 8-byte epilogue stores, 24 / 10 = k_tower16s, 1 = round 1; -1 = library default)")
     ap.add_argument("--conv-variant", type=int, default=0, help="diagnostic: 1 = 2 boards/WG, 2 = 4 boards/WG (0 = library default)")
     args = ap.parse_args()
     if args.gpus < 1:
@@ -280,6 +281,8 @@ def run_rank(args):
 
     if args.conv_variant:
         _lib.lib().xq_conv3x3_set_variant(args.conv_variant)
+    if args.tower_variant >= 0:
+        _lib.lib().xq_tower_set_variant(args.tower_variant)
     if args.search_occ:
         _lib.lib().xq_engine_set_search_occupancy(args.search_occ)
     # XQ_BENCH_FORCE_DIST=1 rehearses the RCCL code path (init, all-gather, barrier, all-reduce)
@@ -394,7 +397,7 @@ def run_rank(args):
         if fused:       # k_tower: conv1 + 2*blocks convs + both heads per launch
             n_conv = len(tower_events)
             conv_fl = 2.0 * rows * 90 * (16 * 9 * 128 + 2 * args.blocks * 128 * 9 * 128 + 128 * 40)
-            kname, kdesc = "k_tower", "k_tower16b, hand-written single-launch trunk on v_mfma_f32_16x16x32_bf16: conv3x3(16->128) + %d fused residual convs + 1x1 heads, activations resident in LDS" % (2 * args.blocks)
+            kname, kdesc = "k_tower", "k_tower16b<PAIR>, hand-written single-launch trunk on v_mfma_f32_16x16x32_bf16: conv3x3(16->128) + %d fused residual convs + 1x1 heads, activations resident in LDS" % (2 * args.blocks)
         else:
             n_conv = 2 * args.blocks * len(tower_events)
             conv_fl = 2.0 * rows * 90 * 128 * 9 * 128

@@ -38,7 +38,9 @@ def timeit(fn, it=20):
 fl = 2.0 * G * 90 * (16 * 9 * 128 + 2 * blocks * 128 * 9 * 128 + 128 * 40)
 NAMES = {0: "k_tower (32x32x16)", 1: "k_tower16 (16x16x32, round 1)", 2: "k_tower16b (16x16x32, round 2)",
          3: "k_tower16b with the skip connection on the VALU (comparison)"}
-for variant in (1, 2, 3, 2, 3, 2):
+NAMES[9] = "k_tower16b, 4 boards per 512-thread workgroup sharing one weight stream (experiment)"
+NAMES[10] = "k_tower16s, 4 boards per workgroup in two groups two stage steps apart (experiment)"
+for variant in ((1, 2, 10, 9, 2, 10, 9, 2, 10) if os.environ.get("XQ_BT_SHORT") is None else (2, 10, 2, 10)):
     L.xq_tower_set_variant(variant)
     ms = timeit(lambda: L.xq_tower_nhwc_bf16(*args))
     print("%s G=%d blocks=%d: %.3f ms  %.1f TFLOP/s" % (NAMES[variant], G, blocks, ms, fl / ms / 1e9))
@@ -50,7 +52,7 @@ fn = L.xq_tower_debug_stamps
 fn.argtypes = [C.c_void_p] * 9 + [C.c_int, C.c_int, C.c_void_p]
 nwg = (G + 1) // 2
 stamps = torch.zeros(nwg * 64, dtype=torch.int64, device="cuda")
-if variant in (1, 2):
+if variant in (1, 2) and os.environ.get("XQ_BT_SHORT") is None:
     # ablation builds (results are wrong on purpose): what the weight refills / stage barriers / tap arithmetic cost
     abl = (((1, "stamped build"), (7, "no weight refills"), (4, "no stage barriers"), (5, "neither"),
             (6, "no per-tap address arithmetic")) if variant == 1 else
@@ -68,6 +70,8 @@ for _ in range(2):
     fn(*args, stamps.data_ptr())
 torch.cuda.synchronize()
 s = stamps.cpu().numpy().reshape(nwg, 64).astype(np.float64)
+s = s[s[:, 61] > 0]                                  # (the 4-boards-per-workgroup build fills only half of the rows)
+nwg = len(s)
 nl = 2 * blocks
 tot = s[:, 61] - s[:, 0]
 rt = s[:, 63] - s[:, 62]

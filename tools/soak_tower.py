@@ -13,6 +13,8 @@ from chinesechessai_amd.neural_network import ChessNet, InferenceNet
 L = _lib.lib()
 st = torch.cuda.current_stream().cuda_stream
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+va = int(sys.argv[2]) if len(sys.argv) > 2 else 8        # build under test (run twice) ...
+vb = int(sys.argv[3]) if len(sys.argv) > 3 else 0        # ... and the build it is compared with
 t0, it, worst, nondet = time.time(), 0, 0.0, 0
 gen = torch.Generator().manual_seed(1)
 while time.time() - t0 < budget:
@@ -24,7 +26,7 @@ while time.time() - t0 < budget:
     planes = torch.zeros(G, 10, 9, 16, device="cuda", dtype=torch.bfloat16)
     planes[..., :15] = (torch.rand(G, 10, 9, 15, device="cuda") < 0.15).to(torch.bfloat16)
     outs = []
-    for variant in (2, 0, 2):
+    for variant in (va, vb, va):
         L.xq_tower_set_variant(variant)
         P = torch.empty(G, 2880, device="cuda", dtype=torch.bfloat16)
         V = torch.empty(G, 720, device="cuda", dtype=torch.bfloat16)
@@ -41,6 +43,7 @@ while time.time() - t0 < budget:
     worst = max(worst, err)
     assert err <= 2 ** -6, (it, blocks, G, err)
     it += 1
-L.xq_tower_set_variant(2)
-print("soak: %d nets, worst relative difference between the two builds %.4g, run-to-run mismatches %d" % (it, worst, nondet))
+L.xq_tower_set_variant(8)
+print("soak (build %d vs build %d): %d nets, worst relative difference between the two builds %.4g, run-to-run mismatches %d"
+      % (va, vb, it, worst, nondet))
 assert nondet == 0
