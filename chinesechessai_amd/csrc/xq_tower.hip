@@ -1634,6 +1634,10 @@ static int launch_tower(void *stream, const void *planes, const void *w1, const 
         for (const void *f : { reinterpret_cast<const void *>(&k_tower16s<STAMP>), reinterpret_cast<const void *>(&k_tower16s<STAMP, 0, true>) })
             if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES4S) != hipSuccess) return XQ_E_HIP;
         if (STAMP)
+            for (const void *f : { reinterpret_cast<const void *>(&k_tower16b<true, 1, 2, true>), reinterpret_cast<const void *>(&k_tower16b<true, 2, 2, true>),
+                                   reinterpret_cast<const void *>(&k_tower16b<true, 32, 2, true>) })
+                if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) return XQ_E_HIP;
+        if (STAMP)
             for (const void *f : { reinterpret_cast<const void *>(&k_tower16s<true, 1>), reinterpret_cast<const void *>(&k_tower16s<true, 2>), reinterpret_cast<const void *>(&k_tower16s<true, 2, true>) })
                 if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES4S) != hipSuccess) return XQ_E_HIP;
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tower16b<STAMP, 0, 4>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1648,7 +1652,10 @@ static int launch_tower(void *stream, const void *planes, const void *w1, const 
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int v = g_tower_variant;
     if (STAMP && v >= 4 && v != 8 && v != 9 && v != 10 && v != 24) {        // ablation builds (wrong results, timing only) ride on the stamp entry point
-        if (v == 25) hipLaunchKernelGGL((k_tower16s<true, 2, true>), dim3((n_boards + 3) / 4), dim3(512), LDS_BYTES4S, st, a);   // 16-byte stores + s_setprio 3 in epilogues
+        if (v == 30) hipLaunchKernelGGL((k_tower16b<true, 1, 2, true>), grid, blk, LDS_BYTES, st, a);       // k_tower16b<PAIR>: no refills
+        else if (v == 31) hipLaunchKernelGGL((k_tower16b<true, 2, 2, true>), grid, blk, LDS_BYTES, st, a);  //                   no stage barriers
+        else if (v == 32) hipLaunchKernelGGL((k_tower16b<true, 32, 2, true>), grid, blk, LDS_BYTES, st, a); //                   one filler per MFMA gap (results valid)
+        else if (v == 25) hipLaunchKernelGGL((k_tower16s<true, 2, true>), dim3((n_boards + 3) / 4), dim3(512), LDS_BYTES4S, st, a);   // 16-byte stores + s_setprio 3 in epilogues
         else if (v == 20) hipLaunchKernelGGL((k_tower16s<true, 2>), dim3((n_boards + 3) / 4), dim3(512), LDS_BYTES4S, st, a);   // k_tower16s: s_setprio 3 in epilogues (results valid)
         else if (v == 11) hipLaunchKernelGGL((k_tower16s<true, 1>), dim3((n_boards + 3) / 4), dim3(512), LDS_BYTES4S, st, a);   // k_tower16s: 23 of 24 pixel tiles (power probe)
         else if (v == 7) hipLaunchKernelGGL((k_tower16<true, 1>), grid, blk, LDS_BYTES, st, a);          // k_tower16: no refills
