@@ -19,7 +19,7 @@ positions, per-game seeds base+g.  Games shard across GPUs with no data-path col
 (weak scaling: G per GPU fixed).
 
 Prints ONE JSON line (rank 0).  `roofline` = the dominant kernel of the step, the hand-written
-single-launch trunk k_tower16 (csrc/xq_tower.hip; MFMA-bound, ~85 % of GPU time); `roofline_net` =
+single-launch trunk k_tower16b<PAIR> (csrc/xq_tower.hip; MFMA-bound, ~91 % of GPU time); `roofline_net` =
 the whole network forward; `roofline_tree` = the tree/rules kernel k_search_round (HBM-bound
 integer work); all measured live with events on the stream the kernels run on.
 `cpu_baseline` = the CPU oracle ("port" of the reference algorithm, net on CPU torch) timed on the
@@ -66,7 +66,7 @@ def pmc_traffic(kernel, G, S, blocks, fetch_factor=1.0):
     correction, MI355X_MICROARCH.md); (None, None) for configs that were not profiled."""
     if not (G == 16384 and S == 50 and blocks == 6):
         return None, None
-    for name in ("r02_pmc_kernels.json", "r01g_pmc_kernels.json", "r01f_pmc_kernels.json", "r01d_pmc_kernels.json"):
+    for name in ("r02b_pmc_kernels.json", "r02_pmc_kernels.json", "r01g_pmc_kernels.json", "r01f_pmc_kernels.json", "r01d_pmc_kernels.json"):
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
             doc = json.load(open(path))

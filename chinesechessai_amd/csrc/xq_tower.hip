@@ -886,7 +886,7 @@ __global__ __launch_bounds__(NB * 128, 2) void k_tower16b(TowerArgs A)
         // x + bias = S . X + bias with a 0/1 selector S as the MFMA's A
         // operand (row i of weight tile mt picks input channel (mt & 1) * 16 + i of K-step hc * 2 + (mt >> 1)), X
         // = this wave's own 64 channels of the block input as 12 ordinary B fragments, bias as the C operand:
-        // exact (1.0 * x + zeros in fp32), 24 MFMAs + 12 ds_read_b128 instead of 144 VALU + 24 ds_read_b64 —
+        // one fp32 addition per element (the MFMA adder's rounding, last-bit differences to v_add_f32), 24 MFMAs + 12 ds_read_b128 instead of 144 VALU + 24 ds_read_b64 —
         // an epilogue runs beside the partner wave's MFMA stream, where VALU issue slots are what is scarce.
         bf16x8 xf[2][6], sel[2];
         if constexpr (decltype(read_x)::value && (ABL & 64) == 0) {
@@ -1333,7 +1333,7 @@ __global__ __launch_bounds__(512, 2) void k_tower16s(TowerArgs A)
         // x + bias = S . X + bias with a 0/1 selector S as the MFMA's A
         // operand (row i of weight tile mt picks input channel (mt & 1) * 16 + i of K-step hc * 2 + (mt >> 1)), X
         // = this wave's own 64 channels of the block input as 12 ordinary B fragments, bias as the C operand:
-        // exact (1.0 * x + zeros in fp32), 24 MFMAs + 12 ds_read_b128 instead of 144 VALU + 24 ds_read_b64 —
+        // one fp32 addition per element (the MFMA adder's rounding, last-bit differences to v_add_f32), 24 MFMAs + 12 ds_read_b128 instead of 144 VALU + 24 ds_read_b64 —
         // an epilogue runs beside the partner wave's MFMA stream, where VALU issue slots are what is scarce.
         bf16x8 xf[2][6], sel[2];
         if constexpr (decltype(read_x)::value && (ABL & 64) == 0) {

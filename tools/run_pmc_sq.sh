@@ -1,5 +1,6 @@
 # SQ counter pass over the bench workload (2 plies): MFMA-pipe busy share, LDS conflicts, wait cycles
 set -e
+TAG=${1:-r02}
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 O=$GRAFT_REPO_ROOT/gpurun_out
@@ -10,7 +11,7 @@ C2="SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_VALU SQ_INSTS_S
 timeout -k 10 200 rocprofv3 --pmc $C1 --kernel-trace --output-format csv -d $O/sq1 -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --profile-plies 2 > $O/sq1.log 2>&1 || echo "pass 1 failed"
 timeout -k 10 200 rocprofv3 --pmc $C2 --kernel-trace --output-format csv -d $O/sq2 -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --profile-plies 2 > $O/sq2.log 2>&1 || echo "pass 2 failed"
 cd $GRAFT_REPO_ROOT
-python tools/pmc_summary.py gpurun_out/r02_pmc_sq.json gpurun_out/sq1 gpurun_out/sq2 > gpurun_out/sq_summary.log 2>&1 || true
+python tools/pmc_summary.py gpurun_out/${TAG}_pmc_sq.json gpurun_out/sq1 gpurun_out/sq2 > gpurun_out/sq_summary.log 2>&1 || true
 rm -rf gpurun_out/sq1 gpurun_out/sq2
 grep "k_tower\|k_search_round" gpurun_out/sq_summary.log | cut -c1-900
 tail -3 gpurun_out/sq1.log; tail -3 gpurun_out/sq2.log
