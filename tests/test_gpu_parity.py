@@ -565,7 +565,7 @@ def test_single_launch_trunk_equals_per_layer_kernels(L):
     # the builds of the trunk kernel: 8 = k_tower16b with 16-byte epilogue stores (default; v_mfma_f32_16x16x32_bf16,
     # round 2 issue stream, output channels dealt to the MFMA rows 8 per lane), 2 = the same with 8-byte stores,
     # 3 = 2 with the skip connection on the VALU, 24 / 10 = k_tower16s (4 boards per workgroup, two groups two stages
-    # apart) with / without the 16-byte stores, 9 = 4 boards in lock-step, 1 = k_tower16 (round 1), 0 = k_tower
+    # apart) with / without the 16-byte stores, 9 / 29 = 4 boards in lock-step without / with them, 1 = k_tower16 (round 1), 0 = k_tower
     # (32x32x16); only the last accumulates in the per-layer kernels' order (bit-identical without residual blocks).
     # The smallest net on a cold device comes first: that is where a missing DMA wait showed in round 1.
     same_bits = {}
@@ -575,6 +575,7 @@ def test_single_launch_trunk_equals_per_layer_kernels(L):
                                (24, 1, 2), (24, 6, 37), (24, 2, 129), (24, 0, 5), (24, 6, 1), (24, 3, 64), (24, 20, 3), (24, 1, 1022),
                                (10, 1, 2), (10, 6, 37), (10, 2, 129), (10, 0, 5), (10, 6, 1), (10, 3, 64), (10, 20, 3), (10, 1, 1022),
                                (9, 1, 2), (9, 6, 37), (9, 2, 129), (9, 0, 5), (9, 6, 1), (9, 3, 64), (9, 20, 3), (9, 1, 1022),
+                               (29, 1, 2), (29, 6, 37), (29, 2, 129), (29, 0, 5), (29, 20, 3), (29, 1, 1022),
                                (1, 1, 2), (1, 6, 37), (1, 2, 129), (1, 0, 5), (1, 20, 3),
                                (0, 6, 37), (0, 0, 5), (0, 2, 3)):
         L.xq_tower_set_variant(variant)
@@ -601,7 +602,7 @@ def test_single_launch_trunk_equals_per_layer_kernels(L):
         torch.cuda.synchronize()
         assert P0.abs().max().item() > 0
         assert (P1[G] == 9.0).all() and (V1[G] == 9.0).all()
-        if variant in (8, 2, 24, 10, 9):             # one accumulation order: these builds agree to the bit (3 adds the skip
+        if variant in (8, 2, 24, 10, 9, 29):            # one accumulation order: these builds agree to the bit (3 adds the skip
                                                      # connection on the VALU: IEEE add instead of the MFMA adder, last-bit differences)
             ref = same_bits.setdefault((blocks, G), (P1[:G].clone(), V1[:G].clone(), variant))
             assert torch.equal(ref[0].view(torch.int16), P1[:G].view(torch.int16)), (variant, ref[2], blocks, G)
