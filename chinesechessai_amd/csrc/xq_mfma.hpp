@@ -75,6 +75,7 @@ __device__ __forceinline__ void barrier_dma()
 __device__ __forceinline__ bf16x8 lds_ld128(int off) { return *(const XQ_AS3 bf16x8 *)(uint32_t)off; }
 __device__ __forceinline__ f32x4 lds_ldf4(int off) { return *(const XQ_AS3 f32x4 *)(uint32_t)off; }
 __device__ __forceinline__ u32x2 lds_ld64(int off) { return *(const XQ_AS3 u32x2 *)(uint32_t)off; }
+__device__ __forceinline__ u32x4 lds_ld128u(int off) { return *(const XQ_AS3 u32x4 *)(uint32_t)off; }
 __device__ __forceinline__ void lds_st64(int off, uint2 v) { *(XQ_AS3 u32x2 *)(uint32_t)off = u32x2{ v.x, v.y }; }
 __device__ __forceinline__ void lds_st128(int off, uint4 v) { *(XQ_AS3 u32x4 *)(uint32_t)off = u32x4{ v.x, v.y, v.z, v.w }; }
 __device__ __forceinline__ void dma16_abs(const void *gsrc, int lds_off)

@@ -937,7 +937,7 @@ __global__ __launch_bounds__(NB * 128, 2) void k_tower16b(TowerArgs A)
         // x + bias on the matrix pipe as in k_tower16b; the selector follows the channel deal: row i of tile 2j + t
         // picks input channel (i >> 2) * 8 + t * 4 + (i & 3) of K-step hc * 2 + j
         bf16x8 xf[2][6], sel[2];
-        if constexpr (decltype(read_x)::value) {
+        if constexpr (decltype(read_x)::value && (ABL & 64) == 0) {
 #pragma unroll
             for (int k2 = 0; k2 < 2; k2++)
 #pragma unroll
@@ -957,14 +957,21 @@ __global__ __launch_bounds__(NB * 128, 2) void k_tower16b(TowerArgs A)
                 const f32x4 v0 = acc[2 * j][nt], v1 = acc[2 * j + 1][nt];
                 const uint4 pk = make_uint4(relu_bf16x2(pack_bf16x2(v0[0], v0[1])), relu_bf16x2(pack_bf16x2(v0[2], v0[3])),
                                             relu_bf16x2(pack_bf16x2(v1[0], v1[1])), relu_bf16x2(pack_bf16x2(v1[2], v1[3])));
-                if constexpr (decltype(read_x)::value) {
+                if constexpr (decltype(read_x)::value && (ABL & 64) == 0) {
                     acc[2 * j][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sel[0], xf[j][nt], bn0, 0, 0, 0);
                     acc[2 * j + 1][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sel[1], xf[j][nt], bn1, 0, 0, 0);
+                } else if constexpr (decltype(read_x)::value) {       // ABL & 64: the skip connection on the VALU (the lane's own 16 bytes)
+                    const u32x4 x = lds_ld128u(sb[nt] ^ (j << 5));    // same lane, same address: ordered before the store
+                    acc[2 * j][nt] = f32x4{ bf16_lo(x.x) + bn0[0], bf16_hi(x.x) + bn0[1], bf16_lo(x.y) + bn0[2], bf16_hi(x.y) + bn0[3] };
+                    acc[2 * j + 1][nt] = f32x4{ bf16_lo(x.z) + bn1[0], bf16_hi(x.z) + bn1[1], bf16_lo(x.w) + bn1[2], bf16_hi(x.w) + bn1[3] };
                 } else {
                     acc[2 * j][nt] = bn0;
                     acc[2 * j + 1][nt] = bn1;
                 }
                 if (nt < 5 || r < PIX - 80) lds_st128(sb[nt] ^ (j << 5), pk);
+                if constexpr (decltype(read_x)::value && (ABL & 64) != 0) {
+                    if (nt & 1) __builtin_amdgcn_sched_barrier(0);    // (keeps the 12 x loads from being hoisted together: spills)
+                }
             }
         }
         if (ABL & 16) __builtin_amdgcn_s_setprio(0);
@@ -1628,9 +1635,8 @@ static int launch_tower(void *stream, const void *planes, const void *w1, const 
                                    reinterpret_cast<const void *>(&k_tower16b<true, 16>), reinterpret_cast<const void *>(&k_tower16b<true, 32>),
                                    reinterpret_cast<const void *>(&k_tower16b<true, 5>), reinterpret_cast<const void *>(&k_tower16b<true, 64>) })
                 if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) return XQ_E_HIP;
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tower16b<STAMP, 0, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                LDS_BYTES) != hipSuccess)
-            return XQ_E_HIP;
+        for (const void *f : { reinterpret_cast<const void *>(&k_tower16b<STAMP, 0, 2, true>), reinterpret_cast<const void *>(&k_tower16b<STAMP, 64, 2, true>) })
+            if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) return XQ_E_HIP;
         for (const void *f : { reinterpret_cast<const void *>(&k_tower16s<STAMP>), reinterpret_cast<const void *>(&k_tower16s<STAMP, 0, true>) })
             if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES4S) != hipSuccess) return XQ_E_HIP;
         if (STAMP)
@@ -1654,7 +1660,7 @@ static int launch_tower(void *stream, const void *planes, const void *w1, const 
     const dim3 grid((n_boards + 1) / 2), blk(256);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int v = g_tower_variant;
-    if (STAMP && v >= 4 && v != 8 && v != 9 && v != 10 && v != 24 && v != 29) {        // ablation builds (wrong results, timing only) ride on the stamp entry point
+    if (STAMP && v >= 4 && v != 8 && v != 9 && v != 10 && v != 24 && v != 29 && v != 33) {        // ablation builds (wrong results, timing only) ride on the stamp entry point
         if (v == 30) hipLaunchKernelGGL((k_tower16b<true, 1, 2, true>), grid, blk, LDS_BYTES, st, a);       // k_tower16b<PAIR>: no refills
         else if (v == 31) hipLaunchKernelGGL((k_tower16b<true, 2, 2, true>), grid, blk, LDS_BYTES, st, a);  //                   no stage barriers
         else if (v == 32) hipLaunchKernelGGL((k_tower16b<true, 32, 2, true>), grid, blk, LDS_BYTES, st, a); //                   one filler per MFMA gap (results valid)
@@ -1676,6 +1682,7 @@ static int launch_tower(void *stream, const void *planes, const void *w1, const 
         else return XQ_E_INVALID;
     } else if (v == 2) hipLaunchKernelGGL(k_tower16b<STAMP>, grid, blk, LDS_BYTES, st, a);
     else if (v == 3) hipLaunchKernelGGL((k_tower16b<STAMP, 64>), grid, blk, LDS_BYTES, st, a);
+    else if (v == 33) hipLaunchKernelGGL((k_tower16b<STAMP, 64, 2, true>), grid, blk, LDS_BYTES, st, a);  // k_tower16b<PAIR> with the skip connection on the VALU
     else if (v == 8) hipLaunchKernelGGL((k_tower16b<STAMP, 0, 2, true>), grid, blk, LDS_BYTES, st, a);   // k_tower16b + 16-byte epilogue stores
     else if (v == 24) hipLaunchKernelGGL((k_tower16s<STAMP, 0, true>), dim3((n_boards + 3) / 4), dim3(512), LDS_BYTES4S, st, a);   // + 16-byte epilogue stores, conflict-free
     else if (v == 10) hipLaunchKernelGGL(k_tower16s<STAMP>, dim3((n_boards + 3) / 4), dim3(512), LDS_BYTES4S, st, a);   // 4 boards, two groups two stage steps apart

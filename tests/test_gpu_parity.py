@@ -564,7 +564,7 @@ def test_single_launch_trunk_equals_per_layer_kernels(L):
     st = torch.cuda.current_stream().cuda_stream
     # the builds of the trunk kernel: 8 = k_tower16b with 16-byte epilogue stores (default; v_mfma_f32_16x16x32_bf16,
     # round 2 issue stream, output channels dealt to the MFMA rows 8 per lane), 2 = the same with 8-byte stores,
-    # 3 = 2 with the skip connection on the VALU, 24 / 10 = k_tower16s (4 boards per workgroup, two groups two stages
+    # 3 / 33 = 2 / 8 with the skip connection on the VALU, 24 / 10 = k_tower16s (4 boards per workgroup, two groups two stages
     # apart) with / without the 16-byte stores, 9 / 29 = 4 boards in lock-step without / with them, 1 = k_tower16 (round 1), 0 = k_tower
     # (32x32x16); only the last accumulates in the per-layer kernels' order (bit-identical without residual blocks).
     # The smallest net on a cold device comes first: that is where a missing DMA wait showed in round 1.
@@ -572,6 +572,7 @@ def test_single_launch_trunk_equals_per_layer_kernels(L):
     for variant, blocks, G in ((8, 1, 2), (8, 6, 37), (8, 2, 129), (8, 0, 5), (8, 6, 1), (8, 3, 64), (8, 20, 3), (8, 1, 1024),
                                (2, 1, 2), (2, 6, 37), (2, 2, 129), (2, 0, 5), (2, 6, 1), (2, 3, 64), (2, 20, 3), (2, 1, 1024),
                                (3, 1, 2), (3, 6, 37), (3, 2, 129), (3, 20, 3),
+                               (33, 1, 2), (33, 6, 37), (33, 2, 129), (33, 6, 1), (33, 20, 3),
                                (24, 1, 2), (24, 6, 37), (24, 2, 129), (24, 0, 5), (24, 6, 1), (24, 3, 64), (24, 20, 3), (24, 1, 1022),
                                (10, 1, 2), (10, 6, 37), (10, 2, 129), (10, 0, 5), (10, 6, 1), (10, 3, 64), (10, 20, 3), (10, 1, 1022),
                                (9, 1, 2), (9, 6, 37), (9, 2, 129), (9, 0, 5), (9, 6, 1), (9, 3, 64), (9, 20, 3), (9, 1, 1022),

@@ -26,7 +26,8 @@ args = (st, planes.data_ptr(), inet.hip_w[0].data_ptr(), inet.hip_wt.data_ptr(),
 fn = L.xq_tower_debug_stamps
 fn.argtypes = [C.c_void_p] * 9 + [C.c_int, C.c_int, C.c_void_p]
 stamps = torch.zeros((G + 1) // 2 * 64, dtype=torch.int64, device="cuda")
-names = {29: "k_tower16b<PAIR>, 4 boards in lock-step", 9: "k_tower16b, 4 boards in lock-step",
+names = {33: "k_tower16b<PAIR>, skip connection on the VALU",
+         29: "k_tower16b<PAIR>, 4 boards in lock-step", 9: "k_tower16b, 4 boards in lock-step",
          30: "k_tower16b<PAIR>, no weight refills", 31: "k_tower16b<PAIR>, no stage barriers", 32: "k_tower16b<PAIR>, one filler per MFMA gap",
          2: "k_tower16b", 8: "k_tower16b, 16-byte epilogue stores", 10: "k_tower16s", 24: "k_tower16s, 16-byte epilogue stores", 25: "k_tower16s, 16-byte stores, s_setprio 3", 11: "k_tower16s, 23 of 24 pixel tiles", 20: "k_tower16s, s_setprio 3 in epilogues",}
 for variant in [int(v) for v in sys.argv[1:]] or (2, 10, 11, 2, 10, 11, 10, 11):
