@@ -48,17 +48,27 @@ def hipcc_path():
 def build(force=False, verbose=False):
     """Cross-compile the HIP library for gfx950 in-tree (works without a GPU)."""
     deps = SOURCES + HEADERS
+    # XQ_TOWER_PROBES=1 in the environment also compiles the trunk kernel's ablation / option builds (timing probes
+    # behind xq_tower_debug_stamps: tools/bench_tower.py, tools/probe_tiles.py); the default library leaves them out
+    probes = os.environ.get("XQ_TOWER_PROBES", "0") == "1"
+    flagfile = os.path.join(CSRC, "build", "flags.txt")
+    built_with = open(flagfile).read().strip() if os.path.exists(flagfile) else ""
+    if probes and built_with != "probes":
+        force = True                      # (without the request any up-to-date library will do: a probes build is a superset)
     if not force and os.path.exists(LIB_PATH) and all(
             os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
         return LIB_PATH
     # one hipcc per source, concurrently (the trunk kernel alone takes ~2 min), then one link
     flags = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
+    if probes:
+        flags.append("-DXQ_TOWER_PROBES=1")
     objdir = os.path.join(CSRC, "build")
     os.makedirs(objdir, exist_ok=True)
-    jobs = []
+    jobs, tower_rebuilt = [], False
     for src in SOURCES:
         obj = os.path.join(objdir, os.path.basename(src) + ".o")
         if force or not os.path.exists(obj) or any(os.path.getmtime(obj) < os.path.getmtime(d) for d in [src] + HEADERS):
+            tower_rebuilt = tower_rebuilt or src.endswith("xq_tower.hip")
             cmd = [hipcc_path()] + flags + ["-c", "-o", obj, src]
             if verbose:
                 print(" ".join(cmd))
@@ -71,6 +81,8 @@ def build(force=False, verbose=False):
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    with open(flagfile, "w") as f:
+        f.write(("probes" if probes or (built_with == "probes" and not tower_rebuilt) else "default") + "\n")
     return LIB_PATH
 
 

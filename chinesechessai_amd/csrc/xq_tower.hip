@@ -31,6 +31,10 @@
 #include "xq_mfma.hpp"
 #include <type_traits>
 
+#ifndef XQ_TOWER_PROBES
+#define XQ_TOWER_PROBES 0      // 1: also compile the ablation / option builds behind xq_tower_debug_stamps (tools/bench_tower.py, tools/probe_tiles.py)
+#endif
+
 namespace {
 using namespace xqm;
 
@@ -1627,6 +1631,7 @@ static int launch_tower(void *stream, const void *planes, const void *w1, const 
         for (const void *f : { reinterpret_cast<const void *>(&k_tower<STAMP>), reinterpret_cast<const void *>(&k_tower16<STAMP>),
                                reinterpret_cast<const void *>(&k_tower16b<STAMP>), reinterpret_cast<const void *>(&k_tower16b<STAMP, 64>) })
             if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) return XQ_E_HIP;
+#if XQ_TOWER_PROBES
         if (STAMP)
             for (const void *f : { reinterpret_cast<const void *>(&k_tower16<true, 1>), reinterpret_cast<const void *>(&k_tower16<true, 2>),
                                    reinterpret_cast<const void *>(&k_tower16<true, 3>), reinterpret_cast<const void *>(&k_tower16<true, 4>),
@@ -1635,10 +1640,12 @@ static int launch_tower(void *stream, const void *planes, const void *w1, const 
                                    reinterpret_cast<const void *>(&k_tower16b<true, 16>), reinterpret_cast<const void *>(&k_tower16b<true, 32>),
                                    reinterpret_cast<const void *>(&k_tower16b<true, 5>), reinterpret_cast<const void *>(&k_tower16b<true, 64>) })
                 if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) return XQ_E_HIP;
+#endif
         for (const void *f : { reinterpret_cast<const void *>(&k_tower16b<STAMP, 0, 2, true>), reinterpret_cast<const void *>(&k_tower16b<STAMP, 64, 2, true>) })
             if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) return XQ_E_HIP;
         for (const void *f : { reinterpret_cast<const void *>(&k_tower16s<STAMP>), reinterpret_cast<const void *>(&k_tower16s<STAMP, 0, true>) })
             if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES4S) != hipSuccess) return XQ_E_HIP;
+#if XQ_TOWER_PROBES
         if (STAMP)
             for (const void *f : { reinterpret_cast<const void *>(&k_tower16b<true, 1, 2, true>), reinterpret_cast<const void *>(&k_tower16b<true, 2, 2, true>),
                                    reinterpret_cast<const void *>(&k_tower16b<true, 32, 2, true>) })
@@ -1646,6 +1653,7 @@ static int launch_tower(void *stream, const void *planes, const void *w1, const 
         if (STAMP)
             for (const void *f : { reinterpret_cast<const void *>(&k_tower16s<true, 1>), reinterpret_cast<const void *>(&k_tower16s<true, 2>), reinterpret_cast<const void *>(&k_tower16s<true, 2, true>) })
                 if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES4S) != hipSuccess) return XQ_E_HIP;
+#endif
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tower16b<STAMP, 0, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 LDS_BYTES4) != hipSuccess)
             return XQ_E_HIP;
@@ -1661,6 +1669,7 @@ static int launch_tower(void *stream, const void *planes, const void *w1, const 
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int v = g_tower_variant;
     if (STAMP && v >= 4 && v != 8 && v != 9 && v != 10 && v != 24 && v != 29 && v != 33) {        // ablation builds (wrong results, timing only) ride on the stamp entry point
+#if XQ_TOWER_PROBES
         if (v == 30) hipLaunchKernelGGL((k_tower16b<true, 1, 2, true>), grid, blk, LDS_BYTES, st, a);       // k_tower16b<PAIR>: no refills
         else if (v == 31) hipLaunchKernelGGL((k_tower16b<true, 2, 2, true>), grid, blk, LDS_BYTES, st, a);  //                   no stage barriers
         else if (v == 32) hipLaunchKernelGGL((k_tower16b<true, 32, 2, true>), grid, blk, LDS_BYTES, st, a); //                   one filler per MFMA gap (results valid)
@@ -1680,6 +1689,9 @@ static int launch_tower(void *stream, const void *planes, const void *w1, const 
         else if (v == 18) hipLaunchKernelGGL((k_tower16b<true, 5>), grid, blk, LDS_BYTES, st, a);   // no refills, no tap arithmetic
         else if (v == 19) hipLaunchKernelGGL((k_tower16b<true, 64>), grid, blk, LDS_BYTES, st, a);  // comparison: skip connection on the VALU (the form before)
         else return XQ_E_INVALID;
+#else
+        return XQ_E_INVALID;      // timing probes are compiled with -DXQ_TOWER_PROBES=1 only (XQ_TOWER_PROBES=1 in the environment of _lib.build)
+#endif
     } else if (v == 2) hipLaunchKernelGGL(k_tower16b<STAMP>, grid, blk, LDS_BYTES, st, a);
     else if (v == 3) hipLaunchKernelGGL((k_tower16b<STAMP, 64>), grid, blk, LDS_BYTES, st, a);
     else if (v == 33) hipLaunchKernelGGL((k_tower16b<STAMP, 64, 2, true>), grid, blk, LDS_BYTES, st, a);  // k_tower16b<PAIR> with the skip connection on the VALU

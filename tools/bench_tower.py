@@ -6,6 +6,8 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
+# the ablation / option builds exist only in a library compiled with XQ_TOWER_PROBES=1 (build it in the container:
+# XQ_TOWER_PROBES=1 python -c "from chinesechessai_amd import _lib; _lib.build()", the .so travels to the GPU box)
 from chinesechessai_amd import _lib
 from chinesechessai_amd.neural_network import ChessNet, InferenceNet
 
@@ -63,6 +65,9 @@ if variant in (1, 2) and os.environ.get("XQ_BT_SHORT") is None:
             (2, "stamped build again")))
     for v, name in abl:
         L.xq_tower_set_variant(v)
+        if fn(*args, stamps.data_ptr()) != 0:
+            print("%s %s: not in this library (build with XQ_TOWER_PROBES=1)" % (NAMES[variant].split()[0], name))
+            continue
         ms = timeit(lambda: fn(*args, stamps.data_ptr()), it=10)
         print("%s %s: %.3f ms" % (NAMES[variant].split()[0], name, ms))
     L.xq_tower_set_variant(variant)

@@ -9,6 +9,8 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
+# the ablation / option builds exist only in a library compiled with XQ_TOWER_PROBES=1 (build it in the container:
+# XQ_TOWER_PROBES=1 python -c "from chinesechessai_amd import _lib; _lib.build()", the .so travels to the GPU box)
 from chinesechessai_amd import _lib
 from chinesechessai_amd.neural_network import ChessNet, InferenceNet
 
@@ -33,6 +35,9 @@ names = {33: "k_tower16b<PAIR>, skip connection on the VALU",
 for variant in [int(v) for v in sys.argv[1:]] or (2, 10, 11, 2, 10, 11, 10, 11):
     L.xq_tower_set_variant(variant)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    if fn(*args, stamps.data_ptr()) != 0:
+        print("%-36s not in this library (timing probes need a build with XQ_TOWER_PROBES=1)" % names[variant])
+        continue
     for _ in range(3):
         fn(*args, stamps.data_ptr())
     e0.record()
