@@ -15,7 +15,7 @@ from chinesechessai_amd import _lib
 from chinesechessai_amd.neural_network import ChessNet, InferenceNet
 
 L = _lib.lib()
-G, blocks = 16384, 6
+G, blocks = int(os.environ.get("XQ_PROBE_G", "16384")), 6
 st = torch.cuda.current_stream().cuda_stream
 torch.manual_seed(0)
 inet = InferenceNet(ChessNet(num_blocks=blocks).eval().cuda())
