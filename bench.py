@@ -12,7 +12,8 @@ line and exits with the child's code — the counterpart of the reference's pool
 
 A "step" = one pass of the hot path over one batch: G concurrent games per GPU played from the
 start position to the end (rules -> MCTS -> network leaf evaluation -> (state, pi, z) samples),
-plus — for N > 1 — the epoch-end all-gather of the sample records.  Workload at N=1 =
+plus — for N > 1 — the epoch-end all-gather of the sample records (started when the step's last game
+is packed, waited for inside the timed region, running beside the next step's play).  Workload at N=1 =
 BASELINE.json configs[2], the configuration the metric is quoted on (S = 50):
 16,384 concurrent games, 50 sims, 6-block ResNet bf16, random-init weights, synthetic start
 positions, per-game seeds base+g.  Games shard across GPUs with no data-path collective
@@ -228,17 +229,21 @@ def run_rank_rehearsal(args, backend, rank, world):
     G, S = args.games, args.sims
     play = importlib.import_module(standin).make_step(G, S)       # seeds -> uint8 CPU tensor [G * 70 * RECORD_BYTES]
     gathered = [None]
+    pipe = xd.RecordGather(G * 70 * xd.RECORD_BYTES, "cpu")     # the same overlapped gather as run_rank
 
     def step(base_seed):
         local = play(xd.game_seeds(base_seed, G * world, rank, world))
-        gathered[0] = xd.all_gather_records(local)
+        pipe.next_buffer().copy_(local)
+        pipe.launch()
 
     for w in range(args.warmup):
         step(7_000_000 + w * G * world)
+    pipe.drain()
     dist.barrier()
     t0 = time.time()
     for k in range(args.steps):
         step(k * G * world)
+    gathered[0] = pipe.drain()
     dist.barrier()
     t = torch.tensor([time.time() - t0], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -305,6 +310,7 @@ def run_rank(args):
                            fused_tower=bool(args.fused_tower))
     stream = torch.cuda.current_stream().cuda_stream
     records = torch.zeros((args.refill if args.refill else G) * _lib.MAX_PLIES * xd.RECORD_BYTES, dtype=torch.uint8, device="cuda")
+    pipe = xd.RecordGather(records.numel(), "cuda") if use_dist else None
 
     # time the network forward with events on its own (= the engine's) stream
     fw_events = []
@@ -328,16 +334,24 @@ def run_rank(args):
         ev.inet.tower_events = tower_events if timed else None
         seeds = xd.game_seeds(base_seed, TG * world, rank, world)
         if args.refill:
-            step.outcomes, step.plies = eng.play_refill(ev, seeds, records.data_ptr())
+            buf = pipe.next_buffer() if use_dist else records
+            step.outcomes, step.plies = eng.play_refill(ev, seeds, buf.data_ptr())
+            if use_dist:
+                pipe.launch()
         else:
             sched = (lambda ply: 1.0 if ply < args.temp_cutoff else 0.001) if args.temp_cutoff > 0 else None
             eng.play(ev, seeds, read=False, temperature_schedule=sched)
-            eng.pack_samples(records.data_ptr())
-        if use_dist:
-            xd.all_gather_records(records)
+            if use_dist:
+                # the all-gather of this step's samples runs beside the next step's play (two buffers in turn; every
+                # gather is waited for inside the timed region: sync() drains the pipeline before the closing barrier)
+                eng.pack_samples(pipe.next_buffer().data_ptr())
+                pipe.launch()
+            else:
+                eng.pack_samples(records.data_ptr())
 
     def sync():
         if use_dist:
+            pipe.drain()
             dist.barrier()
         torch.cuda.synchronize()
 

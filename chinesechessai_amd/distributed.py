@@ -44,6 +44,47 @@ def all_gather_records(local, group=None):
     return out
 
 
+class RecordGather:
+    """The epoch-end all-gather, overlapped with the next epoch's play (what a training loop does with it: the
+    samples of epoch k travel while epoch k + 1 is being played).  Two local buffers in turn: `next_buffer()`
+    hands out the one whose gather (two epochs ago) has been waited for, `launch()` starts the gather of the
+    buffer just filled (async_op: RCCL's stream first waits for the work already queued on the current stream,
+    i.e. for pack_samples), `drain()` waits for everything in flight and returns the newest gathered tensor.
+    Every byte is gathered exactly as all_gather_records does; only the waiting moves."""
+
+    def __init__(self, nbytes, device, group=None):
+        import torch
+        self.group = group
+        self.buf = [torch.zeros(nbytes, dtype=torch.uint8, device=device) for _ in range(2)]
+        self.out = [None, None]
+        self.work = [None, None]
+        self.k = 0
+
+    def next_buffer(self):
+        i = self.k % 2
+        if self.work[i] is not None:
+            self.work[i].wait()
+            self.work[i] = None
+        return self.buf[i]
+
+    def launch(self):
+        import torch
+        import torch.distributed as dist
+        i = self.k % 2
+        world = dist.get_world_size(self.group)
+        if self.out[i] is None:
+            self.out[i] = torch.empty(world * self.buf[i].numel(), dtype=torch.uint8, device=self.buf[i].device)
+        self.work[i] = dist.all_gather_into_tensor(self.out[i], self.buf[i], group=self.group, async_op=True)
+        self.k += 1
+
+    def drain(self):
+        for i in range(2):
+            if self.work[i] is not None:
+                self.work[i].wait()
+                self.work[i] = None
+        return self.out[(self.k - 1) % 2] if self.k else None
+
+
 def records_to_numpy(t):
     return np.frombuffer(t.detach().cpu().numpy().tobytes(), dtype=RECORD_DTYPE)
 

@@ -67,6 +67,21 @@ def main():
     assert k == num_games
     board, pi, z = xd.record_to_sample(allrec[0, 0, 0])
     assert board.shape == (10, 9) and abs(sum(pi.values()) - 1) < 1e-12 and len(pi) == 44
+    # the overlapped form bench.py uses (RecordGather: two buffers in turn, async gathers): five epochs of distinct
+    # data; every epoch's gathered tensor must equal the synchronous gather of the same bytes, also when it is only
+    # waited for two epochs later
+    pipe = xd.RecordGather(t.numel(), "cpu")
+    want, outs = [], []
+    for epoch in range(5):
+        local_e = torch.roll(t, epoch * 7 + rank) ^ epoch
+        want.append(xd.all_gather_records(local_e))
+        buf = pipe.next_buffer()                       # waits for the gather of epoch - 2
+        if epoch >= 2:
+            assert torch.equal(pipe.out[epoch % 2], want[epoch - 2]), epoch
+        buf.copy_(local_e)
+        pipe.launch()
+    last = pipe.drain()
+    assert torch.equal(last, want[4]) and torch.equal(pipe.out[1], want[3])
     dist.barrier()
     if rank == 0:
         print("DIST_OK world=%d" % world)
