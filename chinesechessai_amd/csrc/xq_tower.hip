@@ -5,7 +5,7 @@
 //
 // Every layer of this network is board-local (zero padding never crosses a board), so a workgroup
 // can carry its boards through all layers without any grid-wide synchronisation: the activations
-// stay in LDS from the input planes to the head outputs, the residual stays in registers, and HBM
+// stay in LDS from the input planes to the head outputs (the residual too: round 1 kept it in registers), and HBM
 // sees 2.9 KB in + 7.2 KB out per board instead of 23 KB in/out (+23 KB residual) per layer.
 // The per-layer kernels of xq_conv.hip spend 18 % of a workgroup's time in those global
 // prologue / epilogue phases (tools/bench_conv.py stamps); here only the weight stream is left.
@@ -24,7 +24,8 @@
 //                        whenever the other arrives early: slower than k_tower16b<PAIR>
 //   k_tower16 (1)        round 1: the same shape, hand-pipelined stage loop
 //   k_tower (0)          v_mfma_f32_32x32x16_bf16, the first version
-// All of them accumulate every output element in the same order: bit-identical results (except k_tower's MFMA shape).
+// The k_tower16b / k_tower16s builds accumulate every output element in the same order and agree to the bit (the builds
+// with the skip connection on the VALU, 3 and 33, and the two older kernels differ in the last bit of some elements).
 // plus diagnostic entry points (phase stamps, ablation builds, bare-MFMA power probes) used by
 // tools/bench_tower.py.  Reference ops: neural_network.py:54-66,181-187 with eval-mode BatchNorm folded.
 #include "../../include/xq_selfplay.h"
