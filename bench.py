@@ -67,7 +67,7 @@ def pmc_traffic(kernel, G, S, blocks, fetch_factor=1.0):
     correction, MI355X_MICROARCH.md); (None, None) for configs that were not profiled."""
     if not (G == 16384 and S == 50 and blocks == 6):
         return None, None
-    for name in ("r02b_pmc_kernels.json", "r02_pmc_kernels.json", "r01g_pmc_kernels.json", "r01f_pmc_kernels.json", "r01d_pmc_kernels.json"):
+    for name in ("r02c_pmc_kernels.json", "r02b_pmc_kernels.json", "r02_pmc_kernels.json", "r01g_pmc_kernels.json", "r01f_pmc_kernels.json", "r01d_pmc_kernels.json"):
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
             doc = json.load(open(path))
@@ -185,7 +185,7 @@ def main():
     ap.add_argument("--tree-reuse", action="store_true", help="extension: keep the played move's subtree (no reference oracle)")
     ap.add_argument("--virtual-loss", action="store_true", help="extension: up to 8 distinct leaves per game and round (8x the network rows)")
     ap.add_argument("--fused-tower", type=int, default=1, help="1 = whole trunk in one launch (k_tower), 0 = one launch per convolution")
-    ap.add_argument("--tower-variant", type=int, default=-1, help="diagnostic: trunk kernel build (8 = default, 2 = 8-byte epilogue stores, 24 / 10 = k_tower16s, 1 = round 1; -1 = library default)")
+    ap.add_argument("--tower-variant", type=int, default=-1, help="diagnostic: trunk kernel build (36 = default, 8 = reads clustered, 2 = 8-byte epilogue stores, 24 / 10 = k_tower16s, 1 = round 1; -1 = library default)")
     ap.add_argument("--conv-variant", type=int, default=0, help="diagnostic: 1 = 2 boards/WG, 2 = 4 boards/WG (0 = library default)")
     args = ap.parse_args()
     if args.gpus < 1:

@@ -13,7 +13,7 @@
 // Same tiling as k_conv3x3_b variant B: workgroup = 4 waves = 2 boards x 2 output-channel halves,
 // wave tile 96 pixels x 64 channels, weights streamed by LDS-DMA in K-slices [128 cout][64 cin]
 // through a double buffer, 80.1 KB LDS -> 2 workgroups per CU.  Builds of that dataflow (xq_tower_set_variant):
-//   k_tower16b<PAIR> (8) round 2, the default: v_mfma_f32_16x16x32_bf16, fully unrolled issue stream; the output channels are
+//   k_tower16b<PAIR> (36, 8) round 2, the default (36: one read / DMA piece per MFMA gap; 8: clustered in front of a tile's MFMAs): v_mfma_f32_16x16x32_bf16, fully unrolled issue stream; the output channels are
 //                        dealt to the MFMA rows so that a lane owns 8 consecutive channels of a pixel and the epilogue
 //                        stores 16 bytes per lane, conflict-free (the 8-byte stores of the first build, variant 2, were
 //                        4-way conflicted on the 32 store banks: all of the kernel's LDS conflicts)
@@ -1616,7 +1616,7 @@ __global__ __launch_bounds__(512, 2) void k_tower16s(TowerArgs A)
 
 }  // namespace
 
-static int g_tower_variant = 8;     // 8 = k_tower16b with 16-byte epilogue stores (default), 2 = k_tower16b as first built (8-byte stores), 10 / 24 = k_tower16s without / with them, 9 = k_tower16b<.., NB = 4> (4 boards in lock-step), 1 = k_tower16, 0 = k_tower (32x32x16); 4..7, 11..20, 25 = timing probes on the stamp entry
+static int g_tower_variant = 36;    // 36 = k_tower16b<PAIR> with one filler per MFMA gap (default), 8 = the same with the fillers clustered, 2 = k_tower16b as first built (8-byte stores), 10 / 24 = k_tower16s without / with the 16-byte stores, 9 / 29 = 4 boards in lock-step, 3 / 33 = skip connection on the VALU, 1 = k_tower16, 0 = k_tower (32x32x16); 4..7, 11..20, 25, 30..32 = timing probes (XQ_TOWER_PROBES builds)
 // diagnostic switch (not part of the public ABI): both kernels compute the same function
 extern "C" void xq_tower_set_variant(int v) { g_tower_variant = v; }
 
@@ -1642,7 +1642,8 @@ static int launch_tower(void *stream, const void *planes, const void *w1, const 
                                    reinterpret_cast<const void *>(&k_tower16b<true, 5>), reinterpret_cast<const void *>(&k_tower16b<true, 64>) })
                 if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) return XQ_E_HIP;
 #endif
-        for (const void *f : { reinterpret_cast<const void *>(&k_tower16b<STAMP, 0, 2, true>), reinterpret_cast<const void *>(&k_tower16b<STAMP, 64, 2, true>) })
+        for (const void *f : { reinterpret_cast<const void *>(&k_tower16b<STAMP, 0, 2, true>), reinterpret_cast<const void *>(&k_tower16b<STAMP, 64, 2, true>),
+                               reinterpret_cast<const void *>(&k_tower16b<STAMP, 32, 2, true>) })
             if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) return XQ_E_HIP;
         for (const void *f : { reinterpret_cast<const void *>(&k_tower16s<STAMP>), reinterpret_cast<const void *>(&k_tower16s<STAMP, 0, true>) })
             if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES4S) != hipSuccess) return XQ_E_HIP;
@@ -1669,7 +1670,7 @@ static int launch_tower(void *stream, const void *planes, const void *w1, const 
     const dim3 grid((n_boards + 1) / 2), blk(256);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int v = g_tower_variant;
-    if (STAMP && v >= 4 && v != 8 && v != 9 && v != 10 && v != 24 && v != 29 && v != 33) {        // ablation builds (wrong results, timing only) ride on the stamp entry point
+    if (STAMP && v >= 4 && v != 8 && v != 9 && v != 10 && v != 24 && v != 29 && v != 33 && v != 36) {        // ablation builds (wrong results, timing only) ride on the stamp entry point
 #if XQ_TOWER_PROBES
         if (v == 30) hipLaunchKernelGGL((k_tower16b<true, 1, 2, true>), grid, blk, LDS_BYTES, st, a);       // k_tower16b<PAIR>: no refills
         else if (v == 31) hipLaunchKernelGGL((k_tower16b<true, 2, 2, true>), grid, blk, LDS_BYTES, st, a);  //                   no stage barriers
@@ -1695,6 +1696,7 @@ static int launch_tower(void *stream, const void *planes, const void *w1, const 
 #endif
     } else if (v == 2) hipLaunchKernelGGL(k_tower16b<STAMP>, grid, blk, LDS_BYTES, st, a);
     else if (v == 3) hipLaunchKernelGGL((k_tower16b<STAMP, 64>), grid, blk, LDS_BYTES, st, a);
+    else if (v == 36) hipLaunchKernelGGL((k_tower16b<STAMP, 32, 2, true>), grid, blk, LDS_BYTES, st, a);  // k_tower16b<PAIR> with one filler per MFMA gap
     else if (v == 33) hipLaunchKernelGGL((k_tower16b<STAMP, 64, 2, true>), grid, blk, LDS_BYTES, st, a);  // k_tower16b<PAIR> with the skip connection on the VALU
     else if (v == 8) hipLaunchKernelGGL((k_tower16b<STAMP, 0, 2, true>), grid, blk, LDS_BYTES, st, a);   // k_tower16b + 16-byte epilogue stores
     else if (v == 24) hipLaunchKernelGGL((k_tower16s<STAMP, 0, true>), dim3((n_boards + 3) / 4), dim3(512), LDS_BYTES4S, st, a);   // + 16-byte epilogue stores, conflict-free

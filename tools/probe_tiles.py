@@ -63,4 +63,4 @@ for variant in [int(v) for v in sys.argv[1:]] or (2, 10, 11, 2, 10, 11, 10, 11):
                                                       np.median(s[:, 56] - s[:, 54]), np.median(s[:, 59] - s[:, 57]),
                                                       np.median(s[:, 57] - s[:, 54])))
     stamps.zero_()
-L.xq_tower_set_variant(8)
+L.xq_tower_set_variant(36)

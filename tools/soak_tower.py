@@ -13,7 +13,7 @@ from chinesechessai_amd.neural_network import ChessNet, InferenceNet
 L = _lib.lib()
 st = torch.cuda.current_stream().cuda_stream
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
-va = int(sys.argv[2]) if len(sys.argv) > 2 else 8        # build under test (run twice) ...
+va = int(sys.argv[2]) if len(sys.argv) > 2 else 36       # build under test (run twice) ...
 vb = int(sys.argv[3]) if len(sys.argv) > 3 else 0        # ... and the build it is compared with
 t0, it, worst, nondet = time.time(), 0, 0.0, 0
 gen = torch.Generator().manual_seed(1)
@@ -43,7 +43,7 @@ while time.time() - t0 < budget:
     worst = max(worst, err)
     assert err <= 2 ** -6, (it, blocks, G, err)
     it += 1
-L.xq_tower_set_variant(8)
+L.xq_tower_set_variant(36)
 print("soak (build %d vs build %d): %d nets, worst relative difference between the two builds %.4g, run-to-run mismatches %d"
       % (va, vb, it, worst, nondet))
 assert nondet == 0

@@ -50,4 +50,4 @@ for G in (64, 256, 512, 1024, 1536, 2048, 3072, 4096, 8192, 16384):
     print("G=%6d  16b: back-to-back %.4f / %.4f ms, single %.4f ms | 16s: back-to-back %.4f / %.4f ms, single %.4f ms | 16s/16b %.3f"
           % (G, res[2][0][0], res[2][1][0], res[2][1][1], res[VB][0][0], res[VB][1][0], res[VB][1][1],
              min(x[0] for x in res[VB]) / min(x[0] for x in res[2])), flush=True)
-L.xq_tower_set_variant(8)
+L.xq_tower_set_variant(36)

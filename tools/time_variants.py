@@ -27,7 +27,7 @@ def run(v, P, V):
 
 P0 = torch.empty(G, 2880, device="cuda", dtype=torch.bfloat16)
 V0 = torch.empty(G, 720, device="cuda", dtype=torch.bfloat16)
-_lib.check(run(8, P0, V0))
+_lib.check(run(36, P0, V0))
 for v in variants:
     P = torch.empty(G, 2880, device="cuda", dtype=torch.bfloat16)
     V = torch.empty(G, 720, device="cuda", dtype=torch.bfloat16)
@@ -45,4 +45,4 @@ for v in variants:
     ms = e0.elapsed_time(e1) / 20
     same = torch.equal(P, P0) and torch.equal(V, V0)
     print("variant %2d: %.3f ms  %.1f TFLOP/s  %s" % (v, ms, fl / ms / 1e9, "== default build" if same else "differs from the default build"), flush=True)
-L.xq_tower_set_variant(8)
+L.xq_tower_set_variant(36)
