@@ -16,6 +16,7 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 va = int(sys.argv[2]) if len(sys.argv) > 2 else 36       # build under test (run twice) ...
 vb = int(sys.argv[3]) if len(sys.argv) > 3 else 0        # ... and the build it is compared with
 t0, it, worst, nondet = time.time(), 0, 0.0, 0
+last_print = t0
 gen = torch.Generator().manual_seed(1)
 while time.time() - t0 < budget:
     blocks = int(torch.randint(0, 7, (1,), generator=gen))
@@ -43,6 +44,9 @@ while time.time() - t0 < budget:
     worst = max(worst, err)
     assert err <= 2 ** -6, (it, blocks, G, err)
     it += 1
+    if time.time() - last_print > 60:                      # (a silent GPU command is taken to be hung after 7 minutes)
+        last_print = time.time()
+        print("  ... %d nets, worst %.4g, mismatches %d" % (it, worst, nondet), flush=True)
 L.xq_tower_set_variant(36)
 print("soak (build %d vs build %d): %d nets, worst relative difference between the two builds %.4g, run-to-run mismatches %d"
       % (va, vb, it, worst, nondet))
