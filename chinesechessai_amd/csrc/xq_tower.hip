@@ -1811,6 +1811,7 @@ __global__ __launch_bounds__(256, 2) void k_mfma_probe(const uint32_t *seed, con
 // the same bare loop on v_mfma_f32_16x16x32_bf16 (24 accumulators of 4 registers: the same 96 x 64
 // output tile per wave, the same FLOPs per iteration): which shape the chip clocks higher on
 namespace {
+template <int ORDER>        // 0: pixel tile outer, weight tile inner (the kernels' order: B operand constant over 4 MFMAs); 1: weight tile outer (A constant over 6)
 __global__ __launch_bounds__(256, 2) void k_mfma_probe16(const uint32_t *seed, float *out, int iters)
 {
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1829,11 +1830,19 @@ __global__ __launch_bounds__(256, 2) void k_mfma_probe16(const uint32_t *seed, f
     const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     for (int it = 0; it < iters; it++) {
 #pragma unroll
-        for (int u = 0; u < 2; u++)
+        for (int u = 0; u < 2; u++) {
+            if (ORDER == 0) {
 #pragma unroll
-            for (int n = 0; n < 6; n++)
+                for (int n = 0; n < 6; n++)
 #pragma unroll
-                for (int m = 0; m < 4; m++) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m], b[n], acc[m][n], 0, 0, 0);
+                    for (int m = 0; m < 4; m++) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m], b[n], acc[m][n], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int m = 0; m < 4; m++)
+#pragma unroll
+                    for (int n = 0; n < 6; n++) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m], b[n], acc[m][n], 0, 0, 0);
+            }
+        }
     }
     float t = 0.f;
     for (int m = 0; m < 4; m++) for (int n = 0; n < 6; n++) for (int i = 0; i < 4; i++) t += acc[m][n][i];
@@ -1850,7 +1859,11 @@ extern "C" int xq_mfma_probe(void *stream, const void *seed64_dev, const void *w
 {
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (mode == 16) {       // 48 MFMAs of 16x16x32 per iteration = the FLOPs of 24 of 32x32x16
-        hipLaunchKernelGGL(k_mfma_probe16, dim3(n_workgroups), dim3(256), 0, st, (const uint32_t *)seed64_dev, (float *)out_dev, iters);
+        hipLaunchKernelGGL(k_mfma_probe16<0>, dim3(n_workgroups), dim3(256), 0, st, (const uint32_t *)seed64_dev, (float *)out_dev, iters);
+        return hipGetLastError() == hipSuccess ? 0 : XQ_E_HIP;
+    }
+    if (mode == 17) {       // the same with the weight tile in the outer loop
+        hipLaunchKernelGGL(k_mfma_probe16<1>, dim3(n_workgroups), dim3(256), 0, st, (const uint32_t *)seed64_dev, (float *)out_dev, iters);
         return hipGetLastError() == hipSuccess ? 0 : XQ_E_HIP;
     }
     const int lds_bytes = mode ? 80128 : 0;
