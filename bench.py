@@ -19,10 +19,17 @@ BASELINE.json configs[2], the configuration the metric is quoted on (S = 50):
 positions, per-game seeds base+g.  Games shard across GPUs with no data-path collective
 (weak scaling: G per GPU fixed).
 
+The headline runs with the result-identical root evaluation carry-over (the new root's priors are the ones the
+played child received during the previous ply's search: 6 network forwards per ply instead of the reference's 7,
+games bit-identical, tests/test_gpu_round3.py) and evaluator row compaction (slots without a pending leaf are not
+network rows); `value_no_carry` (every root evaluated afresh, as the reference does) and
+`value_full_policy_head` (all 8,100 policy columns) are measured beside it on a few extra steps.
+
 Prints ONE JSON line (rank 0).  `roofline` = the dominant kernel of the step, the hand-written
-single-launch trunk k_tower16b<PAIR> (csrc/xq_tower.hip; MFMA-bound, ~91 % of GPU time); `roofline_net` =
-the whole network forward; `roofline_tree` = the tree/rules kernel k_search_round (HBM-bound
-integer work); all measured live with events on the stream the kernels run on.
+single-launch trunk k_tower16b<PAIR> (csrc/xq_tower.hip; MFMA-bound, ~90 % of GPU time), over its full-size
+launches (rows = games; the carried-over rounds launch it with zero rows and are listed apart); `roofline_net` =
+the whole network forward over all launches and the rows they really evaluated; `roofline_tree` = the tree/rules
+kernel k_search_round (HBM-bound integer work); all measured live with events on the stream the kernels run on.
 `cpu_baseline` = the CPU oracle ("port" of the reference algorithm, net on CPU torch) timed on the
 host cores on a bounded sample (rank 0, N = 1 only).
 """
@@ -83,7 +90,7 @@ def pmc_traffic(kernel, G, S, blocks, fetch_factor=1.0):
 # CPU baseline: the oracle (C restatement of the reference algorithm) with the net on CPU torch
 # ------------------------------------------------------------------------------------------
 def _cpu_worker(args):
-    idx, blocks, sims, threads, plies, games, reps, barrier = args
+    idx, blocks, sims, threads, rep_plies, games, barrier = args
     import torch
     torch.set_num_threads(threads)
     from chinesechessai_amd.neural_network import ChessNet
@@ -110,7 +117,7 @@ def _cpu_worker(args):
     xo.lib()
     xo.self_play_game(999, sims, eval_red=ev, max_moves=1)          # first touch (untimed)
     out = []
-    for rep in range(reps):
+    for rep, plies in enumerate(rep_plies):
         barrier.wait()                                               # pool start-up is outside every timed span
         t0 = time.time()
         n_plies = 0
@@ -122,34 +129,42 @@ def _cpu_worker(args):
     return out
 
 
-def cpu_baseline(blocks, sims, workers=4, plies=18, games=8, reps=3, max_cores=16):
+def cpu_baseline(blocks, sims, workers=4, plies=18, games=8, reps=3, max_cores=16, whole_game_reps=1):
     """The structural twin of the reference's 4-process path (NUM_WORKERS = 4, config.py:48;
     self_play.py:404-408): 4 worker processes, each playing `games` games one after the other with a
     private net replica on CPU torch, intra-op threads pinned to cores/4 (the reference's unpinned
     default oversubscribes).  Timing rule of SURVEY.md §8(d): >= 8 games per worker,
     pool start-up and first touch excluded, median of 3 repetitions.  Bounded sample: the first
     `plies` plies of every game, scaled to games/s by plies/70 (random-init games run to the 70-ply
-    cap at a near-constant cost per ply); --cpu-baseline-full plays whole games (~100 s)."""
+    cap at a near-constant cost per ply) - and `whole_game_reps` of the repetitions play WHOLE 70-ply
+    games, so the extrapolation is checked inside the same run (`whole_games` in the result);
+    --cpu-baseline-full plays whole games in every repetition."""
     import multiprocessing as mp
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 4)
     cores = min(cores, max_cores)                 # the box's CPU share for one GPU
     threads = max(1, cores // workers)
+    rep_plies = [plies] * reps
+    for k in range(min(whole_game_reps, reps)):
+        rep_plies[reps - 1 - k] = 70
     ctx = mp.get_context("spawn")
     mgr = ctx.Manager()
     barrier = mgr.Barrier(workers)
     with ctx.Pool(workers) as pool:
-        res = pool.map(_cpu_worker, [(i, blocks, sims, threads, plies, games, reps, barrier) for i in range(workers)])
+        res = pool.map(_cpu_worker, [(i, blocks, sims, threads, rep_plies, games, barrier) for i in range(workers)])
     rates, walls = [], []
     for rep in range(reps):
         wall = max(r[rep][0] for r in res)
         rates.append(sum(r[rep][1] for r in res) / 70.0 / wall)
         walls.append(wall)
+    whole = [rates[i] for i in range(reps) if rep_plies[i] == 70]
     return {"value": float(np.median(rates)), "unit": "games/s", "cores": workers * threads, "kind": "port",
-            "sample": "%d worker processes x %d games each, the first %d plies of every game (oracle C rules+MCTS, %d sims, "
-                      "%d-block net fp32 on CPU torch, %d threads each, duplicate leaf rows evaluated as the reference "
-                      "does), scaled by plies/70; median of %d repetitions (%s games/s; walls %s s), pool start-up and "
-                      "first touch excluded" % (workers, games, plies, sims, blocks, threads, reps,
-                                                ", ".join("%.3f" % v for v in rates), ", ".join("%.1f" % v for v in walls))}
+            "whole_games": float(np.median(whole)) if whole else None,
+            "sample": "%d worker processes x %d games each (oracle C rules+MCTS, %d sims, %d-block net fp32 on CPU torch, %d "
+                      "threads each, duplicate leaf rows evaluated as the reference does); %d repetitions, plies played per "
+                      "game in each: %s (a repetition of fewer than 70 plies is scaled by plies/70; the 70-ply ones are whole "
+                      "games and check that scaling); value = median (%s games/s; walls %s s), pool start-up and first touch "
+                      "excluded" % (workers, games, sims, blocks, threads, reps, ", ".join(str(v) for v in rep_plies),
+                                    ", ".join("%.3f" % v for v in rates), ", ".join("%.1f" % v for v in walls))}
 
 
 # ------------------------------------------------------------------------------------------
@@ -178,10 +193,13 @@ def main():
                     help="'reachable' (default): the policy FC computes the 2,294 of 8,100 columns a legal move can index - the "
                          "search gathers legal-move logits only (neural_network.py:148-169), the rest are dead outputs; "
                          "'all': the reference's full 8,100-column head")
-    ap.add_argument("--root-eval-carry", action="store_true",
-                    help="opt-in, result-identical (reported beside the headline, never instead of it): the played child's network "
-                         "evaluation is carried over as the next root's instead of being computed a second time, so round 0 of "
-                         "every ply after the first needs no tree kernel and no network forward (6 forwards per ply instead of 7)")
+    ap.add_argument("--no-root-eval-carry", action="store_true",
+                    help="evaluate every root afresh like the reference (7 forwards per ply).  Default: the result-identical root "
+                         "evaluation carry-over is on (the played child's network evaluation becomes the next root's, 6 forwards "
+                         "per ply); value_no_carry in the JSON line is this mode, measured beside the headline")
+    ap.add_argument("--aux-steps", type=int, default=2,
+                    help="steps for each of the figures measured beside the headline at N = 1 (value_no_carry, "
+                         "value_full_policy_head); 0 = skip them")
     ap.add_argument("--tree-reuse", action="store_true", help="extension: keep the played move's subtree (no reference oracle)")
     ap.add_argument("--virtual-loss", action="store_true", help="extension: up to 8 distinct leaves per game and round (8x the network rows)")
     ap.add_argument("--fused-tower", type=int, default=1, help="1 = whole trunk in one launch (k_tower), 0 = one launch per convolution")
@@ -199,7 +217,10 @@ def launch_ranks(n):
     """`python bench.py --gpus N` with no launcher around it: start the N ranks as a child
     torch.distributed.run (one process per GPU, rendezvous on 127.0.0.1), pass its output through
     and return its exit code.  The child is a subprocess, never an exec; this process has not
-    touched the GPU and never will."""
+    touched the GPU and never will.  SIGTERM / SIGINT to this process are passed on to the child's
+    whole process group (the ranks must not outlive the launcher and keep the GPUs), and the child is
+    torn down on any exception here."""
+    import signal
     import socket
     import subprocess
     s = socket.socket()
@@ -211,7 +232,37 @@ def launch_ranks(n):
     env.setdefault("OMP_NUM_THREADS", "4")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    return subprocess.call(cmd, env=env)
+    child = subprocess.Popen(cmd, env=env, start_new_session=True)      # own process group: one signal reaches every rank
+
+    def stop(signum):
+        try:
+            os.killpg(child.pid, signum)
+        except (ProcessLookupError, PermissionError):
+            pass
+
+    def on_signal(signum, frame):
+        stop(signum)
+        try:
+            child.wait(timeout=20)
+        except subprocess.TimeoutExpired:
+            stop(signal.SIGKILL)
+            child.wait()
+        sys.exit(128 + signum)
+
+    old = {sg: signal.signal(sg, on_signal) for sg in (signal.SIGTERM, signal.SIGINT)}
+    try:
+        return child.wait()
+    except BaseException:
+        stop(signal.SIGTERM)
+        try:
+            child.wait(timeout=20)
+        except subprocess.TimeoutExpired:
+            stop(signal.SIGKILL)
+            child.wait()
+        raise
+    finally:
+        for sg, h in old.items():
+            signal.signal(sg, h)
 
 
 def run_rank_rehearsal(args, backend, rank, world):
@@ -290,7 +341,7 @@ def run_rank(args):
         _lib.lib().xq_tower_set_variant(args.tower_variant)
     if args.search_occ:
         _lib.lib().xq_engine_set_search_occupancy(args.search_occ)
-    # XQ_BENCH_FORCE_DIST=1 rehearses the RCCL code path (init, all-gather, barrier, all-reduce)
+    # XQ_BENCH_FORCE_DIST=1 rehearses the RCCL code path (init, broadcast, all-gather, barrier, all-reduce)
     # with a single rank under torch.distributed.run
     use_dist = world > 1 or (os.environ.get("XQ_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ)
     if use_dist:
@@ -303,44 +354,58 @@ def run_rank(args):
     dev = torch.cuda.current_device()
     G, S = args.games, args.sims
 
-    torch.manual_seed(0)                                   # same random-init weights on every rank
+    # random-init weights of the architecture: rank 0's (seed 0) are THE weights; every other rank starts from its own
+    # seed and receives rank 0's by broadcast, as a trainer's ranks would at the start of an epoch (the reference
+    # ships the state_dict to every worker, self_play.py:386,394)
+    torch.manual_seed(rank)
     net = ChessNet(num_blocks=args.blocks).eval().cuda()
+    bcast_bytes = xd.broadcast_weights(net, src=0) if use_dist else 0
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-    ev = TorchNetEvaluator(net, dtype=dtype, chunk=args.net_chunk or None, policy_columns=args.policy_columns,
-                           fused_tower=bool(args.fused_tower))
+
+    def make_ev(policy_columns):
+        return TorchNetEvaluator(net, dtype=dtype, chunk=args.net_chunk or None, policy_columns=policy_columns,
+                                 fused_tower=bool(args.fused_tower))
+    ev = make_ev(args.policy_columns)
     stream = torch.cuda.current_stream().cuda_stream
     records = torch.zeros((args.refill if args.refill else G) * _lib.MAX_PLIES * xd.RECORD_BYTES, dtype=torch.uint8, device="cuda")
     pipe = xd.RecordGather(records.numel(), "cuda") if use_dist else None
 
-    # time the network forward with events on its own (= the engine's) stream
-    fw_events = []
-    tower_events = []
-    orig_eval = ev.evaluate
+    # network forward / trunk kernel timed with events on their own (= the engine's) stream
+    class Timed:
+        def __init__(self, ev):
+            self.ev, self.fw, self.tower = ev, [], []
+            self.orig = ev.evaluate
 
-    def timed_eval(engine):
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()
-        out = orig_eval(engine)
-        b.record()
-        fw_events.append((a, b))
-        return out
+        def on(self, timed):
+            if timed:
+                def timed_eval(engine):
+                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    a.record()
+                    out = self.orig(engine)
+                    b.record()
+                    self.fw.append((a, b))
+                    return out
+                self.ev.evaluate = timed_eval
+                self.ev.inet.tower_events = self.tower
+            else:
+                self.ev.evaluate = self.orig
+                self.ev.inet.tower_events = None
 
+    tm = Timed(ev)
     TG = args.refill if args.refill else G                  # games per GPU and step
     if args.refill and (args.refill < G or args.temp_cutoff or args.tree_reuse):
         sys.exit("bench.py: --refill TOTAL needs TOTAL >= --games and no per-ply temperature schedule / tree reuse")
 
-    def step(eng, base_seed, timed):
-        ev.evaluate = timed_eval if timed else orig_eval
-        ev.inet.tower_events = tower_events if timed else None
+    def step(eng, ev_, base_seed):
         seeds = xd.game_seeds(base_seed, TG * world, rank, world)
         if args.refill:
             buf = pipe.next_buffer() if use_dist else records
-            step.outcomes, step.plies = eng.play_refill(ev, seeds, buf.data_ptr())
+            step.outcomes, step.plies = eng.play_refill(ev_, seeds, buf.data_ptr())
             if use_dist:
                 pipe.launch()
         else:
             sched = (lambda ply: 1.0 if ply < args.temp_cutoff else 0.001) if args.temp_cutoff > 0 else None
-            eng.play(ev, seeds, read=False, temperature_schedule=sched)
+            eng.play(ev_, seeds, read=False, temperature_schedule=sched)
             if use_dist:
                 # the all-gather of this step's samples runs beside the next step's play (two buffers in turn; every
                 # gather is waited for inside the timed region: sync() drains the pipeline before the closing barrier)
@@ -356,14 +421,14 @@ def run_rank(args):
         torch.cuda.synchronize()
 
     eng = SelfPlayEngine(G, sims=S, planes_format=ev.planes_format, device=dev, stream=stream)
-    if args.root_eval_carry:
-        eng.set_root_eval_carry(True)
+    if args.no_root_eval_carry:
+        eng.set_root_eval_carry(False)
     if args.tree_reuse:
         eng.set_tree_reuse(True)
     if args.virtual_loss:
         eng.set_virtual_loss(True)
     # one-time initialisation that is not part of any step, so that the timed region is clean even
-    # with --warmup 0: code-object load + GEMM heuristics (one forward on the full-size buffers),
+    # with --warmup 0: code-object load (one forward on the full-size buffers),
     # RCCL communicator set-up (one tiny all-gather)
     ev.bind(eng)
     ev.evaluate(eng)
@@ -379,42 +444,87 @@ def run_rank(args):
         saved = eng.max_moves
         if args.warmup_plies > 0:
             eng.max_moves = args.warmup_plies
-        step(eng, 7_000_000 + w * TG * world, False)
+        step(eng, ev, 7_000_000 + w * TG * world)
         eng.max_moves = saved
     sync()
+    eng.row_history(cap=0, reset=True)
     eng.profile(True)
+    tm.on(True)
     t0 = time.time()
     for k in range(args.steps):
-        step(eng, k * TG * world, True)
+        step(eng, ev, k * TG * world)
     sync()
     dt = time.time() - t0
+    tm.on(False)
     prof = eng.profile_read()
-    fw_ms = sum(a.elapsed_time(b) for a, b in fw_events)
-    n_fw = len(fw_events)
+    carry_on = eng._carry_on
+    rows_hist, n_rounds = eng.row_history(reset=True) if eng.row_compaction else (None, 0)
+    fw_t = np.array([a.elapsed_time(b) for a, b in tm.fw])
+    tw_t = np.array([a.elapsed_time(b) for a, b in tm.tower])
+    fw_ms, n_fw = float(fw_t.sum()), len(fw_t)
     outcomes = step.outcomes if args.refill else eng.read_game_outcomes()
     t = torch.tensor([dt], dtype=torch.float64, device="cuda")
     if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
 
+    # ---- beside the headline (N = 1 only, a few steps each, outside the timed region): every root evaluated afresh
+    # like the reference (no carry-over), and the full 8,100-column policy head
+    aux = {}
+    if world == 1 and args.aux_steps > 0 and not args.profile_plies and not args.refill:
+        def timed_steps(ev_, base):
+            torch.cuda.synchronize()
+            ta = time.time()
+            for k in range(args.aux_steps):
+                step(eng, ev_, base + k * TG)
+            torch.cuda.synchronize()
+            return TG * args.aux_steps / (time.time() - ta)
+        if carry_on:
+            eng.set_root_eval_carry(False)
+            step(eng, ev, 8_000_000)                                   # (untimed: first step after the switch)
+            aux["value_no_carry"] = timed_steps(ev, 8_100_000)
+            eng.set_root_eval_carry(None)
+        if args.policy_columns == "reachable":
+            ev_all = make_ev("all")
+            step(eng, ev_all, 9_000_000)
+            aux["value_full_policy_head"] = timed_steps(ev_all, 9_100_000)
+            del ev_all
+        aux["aux_note"] = ("games/s over %d extra steps each, same engine, outside the timed region: value_no_carry = every "
+                           "root evaluated afresh (7 forwards per ply, the reference's count; rounds 1 and 2 of this project "
+                           "quoted this form); value_full_policy_head = policy FC on all 8,100 columns (carry-over on)"
+                           % args.aux_steps)
+
     if rank == 0:
         games = TG * world * args.steps
         rows = eng.n_rows                                   # network rows per forward (one per game; x8 slots with virtual loss)
         fl = net_flops_per_row(args.blocks)
         fl -= 2 * 2880 * (8100 - ev.inet.n_policy_real)        # only the policy columns actually computed count (no padding)
-        net_tflops = (fl * rows * n_fw) / (fw_ms * 1e-3) / 1e12 if fw_ms > 0 else 0.0
+        # rows each forward really evaluated (row compaction: device-side counts of every search round, in launch order)
+        if rows_hist is not None and len(rows_hist) == n_fw:
+            rows_fw = rows_hist.astype(np.int64)
+        else:
+            rows_fw = np.full(n_fw, rows, np.int64)
+        net_tflops = float(fl * rows_fw.sum()) / (fw_ms * 1e-3) / 1e12 if fw_ms > 0 else 0.0
         bpd = tree_bytes_per_descent()
         tree_gbs = (bpd * G * prof["search_launches"]) / (prof["search_ms"] * 1e-3) / 1e9 if prof["search_ms"] > 0 else 0.0
-        # dominant kernel: the hand-written fused conv (2 per residual block, 128 -> 128 channels)
+        # dominant kernel: the single-launch trunk (or, with --fused-tower 0, the per-layer conv)
         fused = bool(args.fused_tower) and ev.inet.use_hip_conv
-        conv_ms = sum(a.elapsed_time(b) for a, b in tower_events)
         if fused:       # k_tower: conv1 + 2*blocks convs + both heads per launch
-            n_conv = len(tower_events)
-            conv_fl = 2.0 * rows * 90 * (16 * 9 * 128 + 2 * args.blocks * 128 * 9 * 128 + 128 * 40)
+            per_board = 2.0 * 90 * (16 * 9 * 128 + 2 * args.blocks * 128 * 9 * 128 + 128 * 40)
+            rows_tw = rows_fw if len(tw_t) == len(rows_fw) else np.full(len(tw_t), rows, np.int64)
+            full = rows_tw == rows                              # full-size launches: every slot has a row
+            n_conv = int(full.sum())
+            conv_ms = float(tw_t[full].sum())
+            conv_fl = per_board * rows
+            launches = {"full": n_conv, "empty": int((rows_tw == 0).sum()), "partial": int(((rows_tw > 0) & ~full).sum()),
+                        "empty_ms_avg": float(tw_t[rows_tw == 0].mean()) if (rows_tw == 0).any() else None,
+                        "all_ms": float(tw_t.sum())}
             kname, kdesc = "k_tower", "k_tower16b<PAIR>, hand-written single-launch trunk on v_mfma_f32_16x16x32_bf16: conv3x3(16->128) + %d fused residual convs + 1x1 heads, activations resident in LDS" % (2 * args.blocks)
         else:
-            n_conv = 2 * args.blocks * len(tower_events)
+            n_conv = 2 * args.blocks * len(tw_t)
+            conv_ms = float(tw_t.sum())
             conv_fl = 2.0 * rows * 90 * 128 * 9 * 128
+            launches = None
             kname, kdesc = "k_conv3x3_b<128>", "hand-written fused conv3x3+bias+residual+ReLU"
         conv_tflops = conv_fl * n_conv / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
         tr_tower = pmc_traffic(kname, G, S, args.blocks, fetch_factor=2.0) if rows == G else (None, None)
@@ -425,19 +535,22 @@ def run_rank(args):
         if args.root_noise or args.temp_cutoff:
             extras.append(", Dirichlet root noise %s, temperature 1 -> 0 at ply %d (extensions, no reference oracle)"
                           % (args.root_noise, args.temp_cutoff))
-        if args.root_eval_carry:
-            extras.append("; ROOT EVALUATION CARRY-OVER (opt-in, result-identical: the new root's priors come from the evaluation "
-                          "the played child got during the previous ply's search, %d network forwards in this run instead of %d; "
-                          "reported beside the headline, not instead of it)" % (n_fw, args.steps * 70 * eng.rounds))
+        if carry_on:
+            extras.append("; root evaluation carry-over ON (result-identical, tested at this size: the new root's priors are the "
+                          "ones the played child received during the previous ply's search, so round 0 of every ply after the "
+                          "first has no network rows: %d full-size forwards in this run instead of %d; value_no_carry is the "
+                          "figure with every root evaluated afresh)" % (int((rows_fw == rows).sum()), n_fw))
+        if eng.row_compaction:
+            extras.append("; evaluator row compaction (only slots with a pending leaf are network rows)")
         if args.tree_reuse:
             extras.append(", tree reuse (extension)")
         if args.virtual_loss:
-            extras.append(", virtual loss: %d rows per game and round (extension)" % (rows // G))
+            extras.append(", virtual loss: %d slots per game and round (extension)" % (rows // G))
         if args.refill:
             extras.append("; REFILL mode: %d games per GPU and step through the %d slots, a finished game's slot restarted at "
                           "once (steady state; reported beside the headline lock-step number, not instead of it)" % (args.refill, G))
         workload = "%s%d concurrent games/GPU, %d sims, %d-block ResNet %s, random-init weights, start positions, seeds base+g%s" % (
-            "BASELINE configs[2]: " if (G, S, args.blocks) == (16384, 50, 6) and not args.refill and not args.root_eval_carry else "",
+            "BASELINE configs[2]: " if (G, S, args.blocks) == (16384, 50, 6) and not args.refill else "",
             G, S, args.blocks, args.dtype, "".join(extras))
         out = {
             "metric": "self-play games/sec @ 50 MCTS sims" if S == 50 else "self-play games/sec @ %d MCTS sims" % S,
@@ -447,18 +560,18 @@ def run_rank(args):
             "synthetic; PROFILING RUN truncated to %d plies per step - not a benchmark" % args.profile_plies,
             "config": {"workload": workload,
                        "games_per_gpu": G, "sims": S, "blocks": args.blocks, "max_moves": 70,
-                       "parallelism": "games sharded x%d, all-gather of samples at step end" % world},
+                       "parallelism": "games sharded x%d, weights broadcast from rank 0 (%d bytes), all-gather of samples at step end" % (world, bcast_bytes)},
             "roofline": {"bound": "mfma", "achieved": conv_tflops, "peak": MFMA_PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": conv_tflops / MFMA_PEAK_BF16_TFLOPS,
                          "traffic": tr_tower[0], "traffic_source": tr_tower[1],
-                         "kernel": "%s (%s; %d launches of %d boards, %.4f ms avg; %.0f%% of the step)" % (
+                         "kernel": "%s (%s; %d full-size launches of %d boards, %.4f ms avg; %.0f%% of the step)" % (
                              kname, kdesc, n_conv, rows, conv_ms / max(n_conv, 1), 100.0 * conv_ms / (dt * 1e3)),
-                         "flops_per_launch": conv_fl},
+                         "flops_per_launch": conv_fl, "launches": launches},
             "roofline_net": {"bound": "mfma", "achieved": net_tflops, "peak": MFMA_PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                              "frac": net_tflops / MFMA_PEAK_BF16_TFLOPS, "traffic": None,
-                             "kernel": "whole network forward (%d launches of %d rows, %.3f ms avg)" % (
-                                 n_fw, rows, fw_ms / max(n_fw, 1)),
-                             "flops_per_launch": fl * rows},
+                             "kernel": "whole network forward (%d launches, %d rows evaluated in all, %.3f ms avg over all launches)" % (
+                                 n_fw, int(rows_fw.sum()), fw_ms / max(n_fw, 1)),
+                             "flops_per_row": fl, "rows_evaluated": int(rows_fw.sum())},
             "roofline_tree": {"bound": "hbm", "achieved": tree_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": tree_gbs / HBM_PEAK_GBS, "traffic": tr_tree[0], "traffic_source": tr_tree[1],
                               "kernel": "k_search_round (%d launches, %.3f ms avg)" % (
@@ -469,6 +582,7 @@ def run_rank(args):
             "games": {"mean_plies": float(outcomes["n_plies"].mean()),
                       "draws_by_cap": int((outcomes["reason"] == 8).sum()), "errors": int(outcomes["error"].sum())},
         }
+        out.update(aux)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.blocks, S, plies=70 if args.cpu_baseline_full else 18)
         print(json.dumps(out))

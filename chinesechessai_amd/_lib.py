@@ -155,15 +155,19 @@ _SIGNATURES = {
     "xq_engine_pack_samples": (C.c_int, [C.c_void_p, C.c_void_p]),
     "xq_engine_set_root_eval_carry": (C.c_int, [C.c_void_p, C.c_int]),
     "xq_engine_roots_not_ready": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "xq_engine_set_row_compaction": (C.c_int, [C.c_void_p, C.c_int]),
+    "xq_engine_row_map": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    "xq_engine_read_row_history": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.c_int]),
+    "xq_engine_read_leaf_rows": (C.c_int, [C.c_void_p, C.c_void_p]),
     "xq_engine_refill_begin": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "xq_engine_refill_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "xq_engine_refill_read_games": (C.c_int, [C.c_void_p] * 8),
     "xq_conv3x3_nhwc_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_int, C.c_int, C.c_int]),
     "xq_heads_nhwc_bf16": (C.c_int, [C.c_void_p] * 6 + [C.c_int]),
-    "xq_tower_nhwc_bf16": (C.c_int, [C.c_void_p] * 9 + [C.c_int, C.c_int]),
-    "xq_policy_fc_bf16": (C.c_int, [C.c_void_p] * 5 + [C.c_int, C.c_int, C.c_int]),
-    "xq_value_head_bf16": (C.c_int, [C.c_void_p] * 7 + [C.c_int]),
+    "xq_tower_nhwc_bf16": (C.c_int, [C.c_void_p] * 9 + [C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "xq_policy_fc_bf16": (C.c_int, [C.c_void_p] * 5 + [C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "xq_value_head_bf16": (C.c_int, [C.c_void_p] * 7 + [C.c_int, C.c_void_p]),
     "xq_replay_last_error": (C.c_char_p, []),
     "xq_replay_create": (C.c_int, [C.c_int, C.c_int64, C.POINTER(C.c_void_p)]),
     "xq_replay_destroy": (None, [C.c_void_p]),

@@ -12,6 +12,7 @@
 // 2 output-channel halves per 256-thread workgroup, 2 workgroups per CU).  Since csrc/xq_tower.hip runs
 // the whole trunk in one launch these per-layer kernels are the selectable fallback and the pinned
 // comparison of the trunk kernel.
+#include <atomic>
 #include "../../include/xq_selfplay.h"
 #include "xq_mfma.hpp"
 
@@ -385,11 +386,14 @@ static int launch_t(hipStream_t s, const void *x, const void *w, const void *bia
 {
     constexpr int KSL = CIN >= KSLP ? KSLP : CIN;
     constexpr int LDS = NB * PIX * 256 + 2 * COUT * KSL * 2 + 256 + 512;
-    static bool attr_set = false;
-    if (!attr_set) {
+    // (the opt-in is a per-device property: one bit per device ordinal, per kernel instantiation)
+    static std::atomic<uint64_t> attr_set{ 0 };
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return XQ_E_HIP;
+    if (!(attr_set.load(std::memory_order_acquire) >> dev & 1)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv3x3_b<CIN, NB, KSLP, STAMP, ABLATE>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return XQ_E_HIP;
-        attr_set = true;
+        attr_set.fetch_or(1ull << dev, std::memory_order_release);
     }
     hipLaunchKernelGGL((k_conv3x3_b<CIN, NB, KSLP, STAMP, ABLATE>), dim3((n_boards + NB - 1) / NB), dim3(NB * 128), LDS, s,
                        (const uint16_t *)x, (const uint16_t *)w, (const float *)bias, (const uint16_t *)residual,
@@ -435,12 +439,14 @@ extern "C" int xq_heads_nhwc_bf16(void *stream, const void *x, const void *w, co
     if (!x || !w || !bias || !policy_out || !value_out || n_boards <= 0) return XQ_E_INVALID;
     constexpr int HNB = 2;                                   // 62 KB LDS -> 2 workgroups per CU
     constexpr int LDS = HNB * PIX * 256 + 64 * 256;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::atomic<uint64_t> attr_set{ 0 };                // one bit per device ordinal
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return XQ_E_HIP;
+    if (!(attr_set.load(std::memory_order_acquire) >> dev & 1)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_heads<HNB>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 LDS) != hipSuccess)
             return XQ_E_HIP;
-        attr_set = true;
+        attr_set.fetch_or(1ull << dev, std::memory_order_release);
     }
     hipLaunchKernelGGL(k_heads<HNB>, dim3((n_boards + HNB - 1) / HNB), dim3(HNB * 64), LDS, reinterpret_cast<hipStream_t>(stream),
                        (const uint16_t *)x, (const uint16_t *)w, (const float *)bias, (uint16_t *)policy_out,

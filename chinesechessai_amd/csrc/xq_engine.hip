@@ -94,6 +94,11 @@ struct Eng {
     // nVl counts the pending visits through a node and is folded into PUCT as N + vl, W - vl
     int vloss, leaf_slots;
     uint8_t *nVl;
+    // evaluator row compaction (xq_engine_set_row_compaction): only slots with a pending leaf become network rows.
+    // k_assign_rows numbers them in slot order after every search round: leaf_row[slot] = row or -1,
+    // row_src[row] = slot (where the search kernel wrote the planes), row_count[0] = rows of this round
+    int compact;
+    int32_t *leaf_row, *row_src, *row_count, *row_hist;
 };
 
 struct __align__(16) WaveLds {
@@ -353,18 +358,19 @@ __device__ void consume_eval(const Eng &E, int g, int slot, WaveLds &L, const Tr
         // neural_network.py:148-169: gather the legal logits, float32 softmax over them
         float x0 = -INFINITY, x1 = -INFINITY;
         const int stride = E.col_map ? E.n_cols : XQ_POLICY_SIZE;
+        const int row = E.compact ? E.leaf_row[slot] : slot;          // the network's output row of this leaf
         const int c0 = (E.col_map && lane < n) ? E.col_map[m0] : m0;
         const int c1 = (E.col_map && lane + 64 < n) ? E.col_map[m1] : m1;
         if (eval_kind == XQ_EVAL_LOGITS_F32) {
-            const float *lg = reinterpret_cast<const float *>(ev_a) + (size_t)slot * stride;
+            const float *lg = reinterpret_cast<const float *>(ev_a) + (size_t)row * stride;
             if (lane < n) x0 = lg[c0];
             if (lane + 64 < n) x1 = lg[c1];
-            v = (double)reinterpret_cast<const float *>(ev_v)[slot];
+            v = (double)reinterpret_cast<const float *>(ev_v)[row];
         } else {
-            const uint16_t *lg = reinterpret_cast<const uint16_t *>(ev_a) + (size_t)slot * stride;
+            const uint16_t *lg = reinterpret_cast<const uint16_t *>(ev_a) + (size_t)row * stride;
             if (lane < n) x0 = bf16_to_f32(lg[c0]);
             if (lane + 64 < n) x1 = bf16_to_f32(lg[c1]);
-            v = (double)bf16_to_f32(reinterpret_cast<const uint16_t *>(ev_v)[slot]);
+            v = (double)bf16_to_f32(reinterpret_cast<const uint16_t *>(ev_v)[row]);
         }
         float mx = fmaxf(x0, x1);
 #pragma unroll
@@ -473,7 +479,10 @@ __global__ __launch_bounds__(64) void k_set_roots(Eng E, const int8_t *boards, c
     store_gs(E.gs + g, gs);
     const int K = E.leaf_slots;
     for (int k = lane; k < K; k += 64) { E.leaf_node[(size_t)g * K + k] = LEAF_NONE; E.leaf_mult[(size_t)g * K + k] = 0; }
-    if (lane == 0) E.root_node[g] = 0;
+    if (lane == 0) {
+        E.root_node[g] = 0;
+        if (E.eval_carry) E.root_ready[g] = 0;          // a caller-provided root has no carried evaluation
+    }
 }
 
 __device__ void record_leaf(const Eng &E, int slot, WaveLds &L, const int8_t *bd, int side, int node,
@@ -659,6 +668,36 @@ __global__ __launch_bounds__(64) void k_hashnet(Eng E, int salt)
         E.priors[(size_t)g * MAXM + j] = (float)((h >> 8) % 64u + 1u) / 1024.0f;
     }
     if (lane == 0) E.values[g] = ((double)((h0 >> 4) % 65u) - 32.0) / 64.0;
+}
+
+// Evaluator row compaction: number the slots that hold a pending leaf, in slot order (deterministic), so that the
+// network kernels touch only those rows.  One workgroup of 16 waves walks the G * K slots 1,024 at a time (ballot
+// prefix inside a wave, 16 partial sums through LDS).  row_src[row] = slot tells the trunk kernel where the search
+// kernel wrote that row's planes; leaf_row[slot] tells consume_eval where the row's logits and value are.
+constexpr int ROW_HIST = 65536;
+__global__ __launch_bounds__(1024) void k_assign_rows(Eng E, int n_slots, unsigned seq)
+{
+    __shared__ int wsum[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int base = 0;
+    for (int start = 0; start < n_slots; start += 1024) {
+        const int slot = start + tid;
+        const bool pending = slot < n_slots && E.leaf_node[slot] != LEAF_NONE && !E.gs[slot / E.leaf_slots].done;
+        const unsigned long long m = __ballot(pending);
+        if (lane == 0) wsum[wave] = __popcll(m);
+        __syncthreads();
+        int off = base, total = 0;
+#pragma unroll
+        for (int w = 0; w < 16; w++) { const int c = wsum[w]; off += w < wave ? c : 0; total += c; }
+        if (slot < n_slots) {
+            const int row = pending ? off + __popcll(m & ((1ull << lane) - 1ull)) : -1;
+            E.leaf_row[slot] = row;
+            if (pending) E.row_src[row] = slot;
+        }
+        base += total;
+        __syncthreads();
+    }
+    if (tid == 0) { E.row_count[0] = base; E.row_hist[seq & (ROW_HIST - 1)] = base; }
 }
 
 __global__ __launch_bounds__(64) void k_end_search(Eng E, int eval_kind, const void *ev_a, const void *ev_v)
@@ -1249,7 +1288,8 @@ struct xq_engine {
     int32_t *stage_rn = nullptr;         // [G]
     // refill mode (xq_engine_refill_*)
     double *uni_all = nullptr; int32_t *slot_game = nullptr, *next_game = nullptr; GameS *out_gs = nullptr;
-    int refill_total = 0;
+    int refill_total = 0, refill_cap = 0;     // games of the running session / games the session buffers hold
+    unsigned row_seq = 0;                     // search rounds launched with row compaction (index into row_hist)
     // profiling
     bool prof = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_search, ev_play;
@@ -1303,6 +1343,8 @@ extern "C" int xq_engine_create(const xq_config *cfg, xq_engine **out)
     bad |= dalloc(e, E.leaf_depth, G); bad |= dalloc(e, E.leaf_moves, G * MAXM); bad |= dalloc(e, E.leaf_path, G * PATH_CAP);
     bad |= dalloc(e, E.leaf_board, G * 12); bad |= dalloc(e, E.leaf_side, G);
     bad |= dalloc(e, E.priors, G * MAXM); bad |= dalloc(e, E.values, G);
+    bad |= dalloc(e, E.leaf_row, G); bad |= dalloc(e, E.row_src, G); bad |= dalloc(e, E.row_count, (size_t)1);
+    bad |= dalloc(e, E.row_hist, (size_t)ROW_HIST);
     bad |= dalloc(e, E.s_board, G * XQ_MAX_PLIES * 12); bad |= dalloc(e, E.s_player, G * XQ_MAX_PLIES);
     bad |= dalloc(e, E.s_n, G * XQ_MAX_PLIES); bad |= dalloc(e, E.s_moves, G * XQ_MAX_PLIES * MAXM);
     bad |= dalloc(e, E.s_counts, G * XQ_MAX_PLIES * MAXM); bad |= dalloc(e, E.s_z, G * XQ_MAX_PLIES);
@@ -1498,10 +1540,12 @@ extern "C" int xq_engine_set_tree_reuse(xq_engine *e, int enable)
 extern "C" int xq_engine_set_virtual_loss(xq_engine *e, int enable)
 {
     if (!e) return fail(XQ_E_INVALID, "null engine");
-    HIPCHK(hipSetDevice(e->cfg.device));
     Eng &E = e->E;
+    // every refusal comes before any state changes (an engine that answered XQ_E_INVALID is left as it was)
     const int K = enable ? E.leaf_batch : 1;
     if (K > 64) return fail(XQ_E_INVALID, "virtual loss needs leaf_batch <= 64 (one lane per pending slot)");
+    if (enable && E.eval_carry) return fail(XQ_E_INVALID, "virtual loss cannot be combined with root evaluation carry-over");
+    HIPCHK(hipSetDevice(e->cfg.device));
     if (K != E.leaf_slots) {
         HIPCHK(hipStreamSynchronize(e->stream));
         const size_t S = (size_t)E.G * (size_t)K;
@@ -1510,11 +1554,11 @@ extern "C" int xq_engine_set_virtual_loss(xq_engine *e, int enable)
         bad |= dalloc(e, E.leaf_depth, S); bad |= dalloc(e, E.leaf_moves, S * MAXM); bad |= dalloc(e, E.leaf_path, S * PATH_CAP);
         bad |= dalloc(e, E.leaf_board, S * 12); bad |= dalloc(e, E.leaf_side, S);
         bad |= dalloc(e, E.priors, S * MAXM); bad |= dalloc(e, E.values, S);
+        bad |= dalloc(e, E.leaf_row, S); bad |= dalloc(e, E.row_src, S);
         if (bad) return fail(XQ_E_HIP, "hipMalloc failed while sizing the pending-leaf slots");
         E.leaf_slots = K;
         HIPCHK(hipMemsetAsync(E.leaf_node, 0xff, S * 2, e->stream));        // LEAF_NONE
     }
-    if (enable && E.eval_carry) return fail(XQ_E_INVALID, "virtual loss cannot be combined with root evaluation carry-over");
     E.vloss = enable ? 1 : 0;
     return grow_nodes(e);
 }
@@ -1649,6 +1693,67 @@ extern "C" int xq_engine_search_round(xq_engine *e, int round, int eval_kind, co
 #undef XQ_LAUNCH_SEARCH
     HIPCHK(hipGetLastError());
     if (ev) HIPCHK(hipEventRecord(ev->second, e->stream));
+    if (e->E.compact) {
+        // number the rows the evaluator has to run for this round (outside the k_search_round events)
+        hipLaunchKernelGGL(k_assign_rows, dim3(1), dim3(1024), 0, e->stream, e->E, e->E.G * e->E.leaf_slots, e->row_seq);
+        HIPCHK(hipGetLastError());
+        e->row_seq++;
+    }
+    return 0;
+}
+
+// Evaluator row compaction (default off: row = slot, every slot is evaluated).  When on, every search round is
+// followed by k_assign_rows, the logits / values of a pending leaf are read from row leaf_row[slot], and the
+// evaluator is expected to (1) read the planes of row r at slot row_src[r], (2) write its outputs to row r,
+// (3) stop at row_count[0] rows (xq_engine_row_map hands out the two device pointers; xq_tower_nhwc_bf16,
+// xq_policy_fc_bf16 and xq_value_head_bf16 take them).  Rows are numbered in slot order, so a run is reproducible;
+// results do not depend on the numbering (every kernel of the evaluator is row-independent).  What it buys: games
+// that are over, rounds that found only terminal leaves, roots carried over by xq_engine_set_root_eval_carry and
+// empty virtual-loss slots cost no network time - without a host round trip.  Evaluators that fill
+// xq_engine_priors_ptr (XQ_EVAL_PRIORS) are indexed by slot either way.
+extern "C" int xq_engine_set_row_compaction(xq_engine *e, int enable)
+{
+    if (!e) return fail(XQ_E_INVALID, "null engine");
+    e->E.compact = enable ? 1 : 0;
+    return 0;
+}
+
+extern "C" int xq_engine_row_map(xq_engine *e, const int32_t **row_src_dev, const int32_t **row_count_dev)
+{
+    if (!e || !row_src_dev || !row_count_dev) return fail(XQ_E_INVALID, "null argument");
+    *row_src_dev = e->E.compact ? e->E.row_src : nullptr;
+    *row_count_dev = e->E.compact ? e->E.row_count : nullptr;
+    return 0;
+}
+
+// rows of the last `cap` search rounds (oldest first) and the number of rounds launched since the engine was
+// created or the history was last reset (reset != 0 restarts the count after reading)
+extern "C" int xq_engine_read_row_history(xq_engine *e, int32_t *rows, int cap, int64_t *n_rounds, int reset)
+{
+    if (!e || !n_rounds || cap < 0 || (cap > 0 && !rows)) return fail(XQ_E_INVALID, "bad argument");
+    HIPCHK(hipSetDevice(e->cfg.device));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    const unsigned n = e->row_seq;
+    *n_rounds = n;
+    int take = (int)(n < (unsigned)cap ? n : (unsigned)cap);
+    if (take > ROW_HIST) take = ROW_HIST;
+    if (take > 0) {
+        std::vector<int32_t> ring(ROW_HIST);
+        HIPCHK(hipMemcpy(ring.data(), e->E.row_hist, (size_t)ROW_HIST * 4, hipMemcpyDeviceToHost));
+        for (int i = 0; i < take; i++) rows[i] = ring[(n - (unsigned)take + (unsigned)i) & (ROW_HIST - 1)];
+    }
+    if (reset) e->row_seq = 0;
+    return 0;
+}
+
+extern "C" int xq_engine_read_leaf_rows(xq_engine *e, int32_t *rows /*[G * leaf_slots]*/)
+{
+    if (!e || !rows) return fail(XQ_E_INVALID, "null argument");
+    HIPCHK(hipSetDevice(e->cfg.device));
+    const size_t S = (size_t)e->E.G * e->E.leaf_slots;
+    HIPCHK(hipMemcpyAsync(rows, e->E.leaf_row, S * 4, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if (!e->E.compact) for (size_t i = 0; i < S; i++) rows[i] = (int32_t)i;
     return 0;
 }
 
@@ -1738,10 +1843,11 @@ extern "C" int xq_engine_refill_begin(xq_engine *e, const uint32_t *seeds, int t
     if (e->E.opponent_mode) return fail(XQ_E_INVALID, "refill is not available in opponent (arena) mode: slots are at different plies");
     HIPCHK(hipSetDevice(e->cfg.device));
     const size_t G = (size_t)e->E.G, T = (size_t)total;
-    if (total > e->refill_total) {           // (buffers of an earlier, smaller session stay in e->allocs until destroy)
+    if (total > e->refill_cap) {             // (buffers of an earlier, smaller session stay in e->allocs until destroy)
         if (dalloc(e, e->uni_all, T * XQ_MAX_PLIES) || dalloc(e, e->out_gs, T)) return fail(XQ_E_HIP, "hipMalloc failed");
-        e->refill_total = total;
+        e->refill_cap = total;
     }
+    e->refill_total = total;                 // the session's size, every session: k_refill deals game ids below it only
     if (!e->slot_game && (dalloc(e, e->slot_game, G) || dalloc(e, e->next_game, (size_t)1)))
         return fail(XQ_E_HIP, "hipMalloc failed");
     std::vector<double> u(T * XQ_MAX_PLIES);

@@ -22,6 +22,7 @@
 // so the activations are fetched into that L2 once.
 #include "../../include/xq_selfplay.h"
 #include "xq_mfma.hpp"
+#include <atomic>
 #include <type_traits>
 
 namespace {
@@ -37,6 +38,7 @@ struct FcArgs {
     const float *bias;        // [N]
     uint16_t *out;            // [M][N]
     int M, N, K, ncol;
+    const int32_t *n_rows;    // optional device value: only rows below *n_rows exist (evaluator row compaction)
 };
 
 __global__ __launch_bounds__(512, 2) void k_policy_fc(FcArgs P)
@@ -52,7 +54,10 @@ __global__ __launch_bounds__(512, 2) void k_policy_fc(FcArgs P)
     const int rb = t / P.ncol, cb = t - rb * P.ncol;
     const int m0 = rb * BM, n0 = cb * BN;
     const int K2 = P.K * 2, nst = P.K >> 6;
-    const int rows = P.M - m0 < BM ? P.M - m0 : BM;                   // rows past M read as zeros (buffer bounds)
+    int M = P.M;
+    if (P.n_rows) { const int n = *P.n_rows; M = n < M ? n : M; }
+    if (m0 >= M) return;                                              // compaction: no row in this tile (uniform, before any barrier)
+    const int rows = M - m0 < BM ? M - m0 : BM;                       // rows past M read as zeros (buffer bounds)
     const rsrc_t ra = make_rsrc(P.act + (size_t)m0 * P.K, rows * K2);
     const rsrc_t rw = make_rsrc(P.w + (size_t)n0 * P.K, BN * K2);
 
@@ -156,7 +161,7 @@ __global__ __launch_bounds__(512, 2) void k_policy_fc(FcArgs P)
             const int m = m0 + wm * 64 + mt * 16 + r16;
             const f32x4 v = acc[nt][mt];
             const uint2 pk = make_uint2(pack_bf16x2(v[0] + b4[0], v[1] + b4[1]), pack_bf16x2(v[2] + b4[2], v[3] + b4[3]));
-            if (m < P.M) *reinterpret_cast<uint2 *>(P.out + (size_t)m * P.N + n) = pk;
+            if (m < M) *reinterpret_cast<uint2 *>(P.out + (size_t)m * P.N + n) = pk;
         }
     }
 }
@@ -173,9 +178,11 @@ __global__ __launch_bounds__(512, 2) void k_policy_fc(FcArgs P)
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_value_head(const uint16_t *__restrict__ hv, const uint16_t *__restrict__ w1,
                                                     const float *__restrict__ b1, const float *__restrict__ w2,
-                                                    const float *__restrict__ b2, uint16_t *__restrict__ out, int M)
+                                                    const float *__restrict__ b2, uint16_t *__restrict__ out, int M,
+                                                    const int32_t *__restrict__ n_rows)
 {
     constexpr int K = 720, KP = 736;
+    if (n_rows) { const int n = *n_rows; M = n < M ? n : M; }        // evaluator row compaction
     const int lane = threadIdx.x & 63, r16 = lane & 15, q = lane >> 4;
     const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;
     if (row0 >= M) return;
@@ -211,31 +218,44 @@ __global__ __launch_bounds__(256) void k_value_head(const uint16_t *__restrict__
 
 }  // namespace
 
-/* logits = act . w^T + bias on the engine's stream.  K % 64 == 0, N % 192 == 0 (pad the weight rows). */
-extern "C" int xq_policy_fc_bf16(void *stream, const void *act, const void *w, const void *bias, void *out, int M, int N, int K)
+// hipFuncAttributeMaxDynamicSharedMemorySize is per device: remembered per device ordinal (a process may drive
+// several GPUs, xq_config.device)
+static int fc_lds_opt_in()
+{
+    static std::atomic<uint64_t> done{ 0 };
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return XQ_E_HIP;
+    if (done.load(std::memory_order_acquire) >> dev & 1) return 0;
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_policy_fc), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            FC_LDS_BYTES) != hipSuccess)
+        return XQ_E_HIP;
+    done.fetch_or(1ull << dev, std::memory_order_release);
+    return 0;
+}
+
+/* logits = act . w^T + bias on the engine's stream.  K % 64 == 0, N % 192 == 0 (pad the weight rows).
+ * n_rows_dev (optional): device int32, only rows below it are computed (evaluator row compaction). */
+extern "C" int xq_policy_fc_bf16(void *stream, const void *act, const void *w, const void *bias, void *out, int M, int N, int K,
+                                 const void *n_rows_dev)
 {
     if (!act || !w || !bias || !out || M <= 0 || N <= 0 || K < 64 || (K & 63) || N % BN) return XQ_E_INVALID;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_policy_fc), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                FC_LDS_BYTES) != hipSuccess)
-            return XQ_E_HIP;
-        attr_set = true;
-    }
-    FcArgs a{ (const uint16_t *)act, (const uint16_t *)w, (const float *)bias, (uint16_t *)out, M, N, K, N / BN };
+    if (int rc = fc_lds_opt_in()) return rc;
+    FcArgs a{ (const uint16_t *)act, (const uint16_t *)w, (const float *)bias, (uint16_t *)out, M, N, K, N / BN,
+              (const int32_t *)n_rows_dev };
     const int ntiles = ((M + BM - 1) / BM) * (N / BN);
     hipLaunchKernelGGL(k_policy_fc, dim3(ntiles), dim3(512), FC_LDS_BYTES, reinterpret_cast<hipStream_t>(stream), a);
     return hipGetLastError() == hipSuccess ? 0 : XQ_E_HIP;
 }
 
 /* values[m] = tanh(w2 . relu(w1 . hv[m] + b1) + b2): hv [n_rows][720] bf16 with >= 32 readable bytes behind the last
- * row, w1 [128][736] bf16 (columns 720.. zero), b1 / w2 float32[128], b2 float32[1], values bf16[n_rows]. */
+ * row, w1 [128][736] bf16 (columns 720.. zero), b1 / w2 float32[128], b2 float32[1], values bf16[n_rows].
+ * n_rows_dev (optional): device int32, only rows below it are computed. */
 extern "C" int xq_value_head_bf16(void *stream, const void *hv, const void *w1, const void *b1, const void *w2, const void *b2,
-                                  void *values, int n_rows)
+                                  void *values, int n_rows, const void *n_rows_dev)
 {
     if (!hv || !w1 || !b1 || !w2 || !b2 || !values || n_rows <= 0) return XQ_E_INVALID;
     hipLaunchKernelGGL(k_value_head, dim3((n_rows + 63) / 64), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                        (const uint16_t *)hv, (const uint16_t *)w1, (const float *)b1, (const float *)w2, (const float *)b2,
-                       (uint16_t *)values, n_rows);
+                       (uint16_t *)values, n_rows, (const int32_t *)n_rows_dev);
     return hipGetLastError() == hipSuccess ? 0 : XQ_E_HIP;
 }

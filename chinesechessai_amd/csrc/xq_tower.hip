@@ -30,6 +30,7 @@
 // tools/bench_tower.py.  Reference ops: neural_network.py:54-66,181-187 with eval-mode BatchNorm folded.
 #include "../../include/xq_selfplay.h"
 #include "xq_mfma.hpp"
+#include <atomic>
 #include <type_traits>
 
 #ifndef XQ_TOWER_PROBES
@@ -57,6 +58,10 @@ struct TowerArgs {
     uint16_t *V;               // [G][90][8]
     int G, nblocks;
     unsigned long long *stamps;   // diagnostic builds only: 64 u64 per workgroup
+    // evaluator row compaction (xq_engine_set_row_compaction), both optional: board b reads the planes of row
+    // row_src[b] and only boards below *n_rows exist (device values of the preceding k_assign_rows)
+    const int32_t *row_src;
+    const int32_t *n_rows;
 };
 
 template <bool STAMP>
@@ -82,8 +87,11 @@ __global__ __launch_bounds__(256, 2) void k_tower(TowerArgs A)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wb_ = wave >> 1, hc = wave & 1;                         // board in workgroup, channel half
+    int nrows = A.G;
+    if (A.n_rows) { const int n = *A.n_rows; nrows = n < A.G ? n : A.G; }
+    if ((int)blockIdx.x * 2 >= nrows) return;       // compaction: no row for this workgroup
     const int board = blockIdx.x * 2 + wb_;
-    const bool board_ok = board < A.G;
+    const bool board_ok = board < nrows;
     const int act_off = ACT0 + wb_ * ACT_BYTES;
     const int r32 = lane & 31, h = lane >> 5;
 
@@ -141,7 +149,7 @@ __global__ __launch_bounds__(256, 2) void k_tower(TowerArgs A)
     };
     stage_w1(0, 0);
     if (board_ok) {
-        const uint8_t *src = reinterpret_cast<const uint8_t *>(A.planes) + (size_t)board * PIX * 32;
+        const uint8_t *src = reinterpret_cast<const uint8_t *>(A.planes) + (size_t)(A.row_src ? A.row_src[board] : board) * PIX * 32;
 #pragma unroll
         for (int j = 0; j < 2; j++) {
             const int q0 = (j * 2 + hc) * 64, q = q0 + lane, p = q >> 1, cp = q & 1;
@@ -375,319 +383,6 @@ __global__ __launch_bounds__(256, 2) void k_tower(TowerArgs A)
 
 
 // ------------------------------------------------------------------------------------------
-// The same trunk on v_mfma_f32_16x16x32_bf16.  Same workgroup, wave tile (96 pixels x 64 channels)
-// and LDS budget; 24 accumulators of 4 registers instead of 6 of 16.  Why: under the board's power
-// cap the chip holds a higher clock on this shape (bare loops: 2.18 vs 1.96 PFLOP/s, tools/
-// bench_tower.py; MI355X_MICROARCH.md "DVFS give-back" item 7) at equal cycles per FLOP.
-// Differences that follow from the shape:
-//   * lane = (r16 = lane & 15, q = lane >> 4): a fragment is row r16 of its tile, 16-B chunk q of the
-//     32-channel K-step; ds_read_b128 serves lanes in groups that mix q = 0 / 1 (2 / 3), so the
-//     activation rows are swizzled by chunk ^ ((pixel & 7) << 1) (conflict-free for every tap shift);
-//   * K-step = 32 channels: a weight stage (64 cin) is 2 K-steps; the stage barrier opens the second
-//     one, whose 24 MFMAs cover the DMA refill and the next stage's first fragments;
-//   * MFMAs run pixel-tile-major: the 4 weight fragments of a K-step stay in registers (double
-//     buffered), the 6 activation fragments roll through 3 registers sets two tiles ahead;
-//   * the input conv packs two taps (2 x 16 planes) into one K-step and stages all its weights
-//     (36,864 B, over the still unused activation rows) at once: no barriers inside it.
-// ------------------------------------------------------------------------------------------
-
-// ABL (diagnostic builds only, wrong results): 1 = no weight refills, 2 = no stage barriers, 3 = both,
-// 4 = every tap reads the centre tap's rows (no per-tap address arithmetic)
-template <bool STAMP, int ABL = 0>
-__global__ __launch_bounds__(256, 2) void k_tower16(TowerArgs A)
-{
-    constexpr int ACT0 = 2 * WBUF_BYTES, ZROW = ACT0 + 2 * ACT_BYTES, BIAS = ZROW + 256;   // bias: [2][128] f32
-
-    auto stamp = [&](int slot) {
-        if constexpr (STAMP) {
-            const unsigned long long t = __builtin_amdgcn_s_memtime();
-            if (threadIdx.x == 0) A.stamps[(size_t)blockIdx.x * 64 + slot] = t;
-            if (slot == 0 || slot == 61) {
-                const unsigned long long rt = __builtin_amdgcn_s_memrealtime();
-                if (threadIdx.x == 0) A.stamps[(size_t)blockIdx.x * 64 + (slot == 0 ? 62 : 63)] = rt;
-            }
-        }
-    };
-    stamp(0);
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wb_ = wave >> 1, hc = wave & 1;                         // board in workgroup, channel half
-    const int board = blockIdx.x * 2 + wb_;
-    const bool board_ok = board < A.G;
-    const int act_off = ACT0 + wb_ * ACT_BYTES;
-    const int r16 = lane & 15, q = lane >> 4;
-
-    // tap validity of the 6 pixels of this lane (pixel tile nt: pixel nt * 16 + r16), 9 bits each
-    uint32_t vm[2] = { 0, 0 };
-#pragma unroll
-    for (int nt = 0; nt < 6; nt++) {
-        const int o = nt * 16 + r16;
-        uint32_t m = 0;
-        if (o < PIX) {
-            const int yy = o / 9, xx = o % 9;
-#pragma unroll
-            for (int t = 0; t < 9; t++) {
-                const int dy = t / 3 - 1, dx = t % 3 - 1;
-                if (yy + dy >= 0 && yy + dy < 10 && xx + dx >= 0 && xx + dx < 9) m |= 1u << t;
-            }
-        }
-        vm[nt / 3] |= m << ((nt % 3) * 9);
-    }
-
-    f32x4 acc[4][6];
-    uint2 xres[4][6];                     // block input (residual), packed bf16 in accumulator layout
-    auto zero_acc = [&]() {
-#pragma unroll
-        for (int mt = 0; mt < 4; mt++)
-#pragma unroll
-            for (int nt = 0; nt < 6; nt++)
-#pragma unroll
-                for (int i = 0; i < 4; i++) acc[mt][nt][i] = 0.f;
-    };
-
-    // ---------------------------------------------------------------- input conv (16 -> 128)
-    // LDS during this phase: [0, 36864) all 9 tap slices [128 cout][16 ch] (32-B rows, linear);
-    // each board's planes (90 x 32 B, linear) in the LAST 2,880 B of its activation region
-    const int pl_off = act_off + ACT_BYTES - PIX * 32;
-    if (tid < 16) lds_st128(ZROW + tid * 16, make_uint4(0, 0, 0, 0));
-    if (wave == 1 && lane < 32) dma16_abs(A.bias + lane * 4, BIAS);
-#pragma unroll
-    for (int j = 0; j < 9; j++) {
-        const int piece = wave * 9 + j;
-        dma16_abs(reinterpret_cast<const uint8_t *>(A.w1) + piece * 1024 + lane * 16, piece * 1024);
-    }
-    if (board_ok) {
-        const uint8_t *src = reinterpret_cast<const uint8_t *>(A.planes) + (size_t)board * PIX * 32;
-#pragma unroll
-        for (int j = 0; j < 2; j++) {
-            const int q0 = (j * 2 + hc) * 64, idx = q0 + lane;
-            if (idx < PIX * 2) dma16_abs(src + idx * 16, pl_off + q0 * 16);
-        }
-    }
-    zero_acc();
-    barrier_dma();
-#pragma unroll
-    for (int pair = 0; pair < 5; pair++) {                           // K-step = taps (2 pair, 2 pair + 1) x 16 planes
-        const int tap = 2 * pair + (q >> 1);
-        const bool tap_real = tap < 9;
-        const int tp = tap_real ? tap : 8;
-        const int off = (tp / 3 - 1) * 9 + (tp % 3 - 1);
-        bf16x8 bf[6], af[4];
-#pragma unroll
-        for (int nt = 0; nt < 6; nt++) {
-            const bool ok = tap_real && ((vm[nt / 3] >> ((nt % 3) * 9 + tp)) & 1u);
-            const int sp = nt * 16 + r16 + off;
-            bf[nt] = lds_ld128((ok ? pl_off + sp * 32 : ZROW + (sp & 7) * 32) + (q & 1) * 16);
-        }
-#pragma unroll
-        for (int mt = 0; mt < 4; mt++)
-            af[mt] = lds_ld128((tp * COUT + hc * 64 + mt * 16 + r16) * 32 + (q & 1) * 16);
-#pragma unroll
-        for (int nt = 0; nt < 6; nt++)
-#pragma unroll
-            for (int mt = 0; mt < 4; mt++)
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mt], bf[nt], acc[mt][nt], 0, 0, 0);
-    }
-    barrier_dma();                                                 // every wave is done with planes and tap slices
-    stamp(1);
-
-    // weight stream of the 128-channel layers: as in k_tower (stage g -> buffer g & 1)
-    const int nlayers = 2 * A.nblocks, nstages = nlayers * 18;
-    const rsrc_t wrsrc = make_rsrc(A.wt, nlayers * 9 * COUT * COUT * 2);
-    // piece j of this wave covers rows (wave * 4 + j) * 8 + (lane >> 3) of the stage; its source swizzle
-    // (row >> 1) & 7 = (lane >> 4) ^ ((j & 1) << 2): two per-lane offsets, the rest is scalar
-    const int wsrc_even = (lane >> 3) * 256 + (((lane & 7) ^ (lane >> 4)) << 4), wsrc_odd = wsrc_even ^ 64;
-    auto stage_piece = [&](int g, int buf, int j) {
-        const int soff = (g >> 1) * (COUT * COUT * 2) + (g & 1) * 128 + (wave * 4 + j) * 2048;
-        dma16_buf_abs(wrsrc, (j & 1) ? wsrc_odd : wsrc_even, soff, buf * WBUF_BYTES + (wave * 4 + j) * 1024);
-    };
-    // A fragment (weight tile mt, K-step kk of a stage): abase ^ (kk << 6), + mt * 2048
-    const int abase = (hc * 64 + r16) * 128 + ((q ^ ((r16 >> 1) & 7)) << 4);
-    auto load_a1 = [&](bf16x8 &af, int mt, int sl, int kk) {
-        af = lds_ld128((abase ^ (kk << 6)) + sl * WBUF_BYTES + mt * 2048);
-    };
-    // B fragment (pixel tile nt, K-step ks of the 128 channels): a0[nt] ^ (ks << 6)
-    auto tap_addr1 = [&](int nt, int tap) {
-        if (ABL & 4) tap = 4;                                         // ablation: no per-tap address arithmetic
-        const int off = (tap / 3 - 1) * 9 + (tap % 3 - 1);
-        const bool ok = (vm[nt / 3] >> ((nt % 3) * 9 + tap)) & 1u;
-        const int sp = nt * 16 + r16 + off;
-        // padding lanes read the 256-B zero row at the 16-B slot their own row would have used, so a
-        // ds_read_b128 lane group stays conflict-free whatever the mix of real and padding pixels
-        return (ok ? act_off + sp * 256 : ZROW) + ((q ^ ((sp & 7) << 1)) << 4);
-    };
-    auto load_b1 = [&](bf16x8 &bf, int a, int ks) { bf = lds_ld128(a ^ (ks << 6)); };
-
-    // epilogue: acc + bias [+ residual] -> ReLU -> bf16 -> LDS rows in place (+ keep as next residual)
-    auto epilogue = [&](int lb, auto add_res, auto keep_res) {     // lb: LDS offset of this layer's 128 biases
-        // everything the stores need is re-derived from the lane id here, behind an optimisation
-        // barrier: kept live across the main loop these values cost ~20 registers (spilled)
-        int ln;                                                       // lane id, 2 VALU, not CSE-able
-        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
-        const int r = ln & 15, qq = ln >> 4;
-        int sb[6];
-#pragma unroll
-        for (int nt = 0; nt < 6; nt++) {
-            const int p = nt * 16 + r < PIX ? nt * 16 + r : 0;
-            sb[nt] = act_off + p * 256 + (qq & 1) * 8 + (((hc * 8 + (qq >> 1)) ^ ((p & 7) << 1)) << 4);
-        }
-        const int lbq = lb + (hc * 64 + 4 * qq) * 4;
-#pragma unroll
-        for (int mt = 0; mt < 4; mt++) {
-            const f32x4 b4 = lds_ldf4(lbq + mt * 64);
-#pragma unroll
-            for (int nt = 0; nt < 6; nt++) {
-                float v0 = acc[mt][nt][0] + b4[0], v1 = acc[mt][nt][1] + b4[1];
-                float v2 = acc[mt][nt][2] + b4[2], v3 = acc[mt][nt][3] + b4[3];
-                if constexpr (decltype(add_res)::value) {
-                    const uint2 rr = xres[mt][nt];
-                    v0 += bf16_lo(rr.x); v1 += bf16_hi(rr.x); v2 += bf16_lo(rr.y); v3 += bf16_hi(rr.y);
-                }
-                const uint2 pk = make_uint2(relu_bf16x2(pack_bf16x2(v0, v1)), relu_bf16x2(pack_bf16x2(v2, v3)));
-                if constexpr (decltype(keep_res)::value) xres[mt][nt] = pk;
-                if (nt < 5 || r < PIX - 80) lds_st64(sb[nt] ^ (mt << 5), pk);
-            }
-        }
-    };
-    using yes = std::integral_constant<bool, true>;
-    using no = std::integral_constant<bool, false>;
-
-    if (nstages > 0) {
-#pragma unroll
-        for (int j = 0; j < 4; j++) { stage_piece(0, 0, j); stage_piece(1, 1, j); }
-        if (wave == 1 && lane < 32) dma16_abs(A.bias + 128 + lane * 4, BIAS + 512);
-    }
-    epilogue(BIAS, no{}, yes{});
-    barrier_dma();
-    stamp(2);
-
-    // ---------------------------------------------------------------- residual tower
-    bf16x8 fa[2][4], fb[3];                                          // weights: K-step parity; activations: rolling
-    if (nstages > 0) {
-#pragma unroll
-        for (int mt = 0; mt < 4; mt++) load_a1(fa[0][mt], mt, 0, 0);
-    }
-    for (int layer = 0; layer < nlayers; layer++) {
-        zero_acc();
-        if (wave == 1 && lane < 32 && layer + 1 < nlayers)          // next layer's bias, slot (layer + 2) & 1
-            dma16_abs(A.bias + (size_t)(layer + 2) * 128 + lane * 4, BIAS + (layer & 1) * 512);
-        int a0[6];                                                  // this tap's row addresses, replaced in place
-#pragma unroll                                                      // by the next tap's as soon as each is dead
-        for (int nt = 0; nt < 6; nt++) a0[nt] = tap_addr1(nt, 0);
-        load_b1(fb[0], a0[0], 0);
-        load_b1(fb[1], a0[1], 0);
-        for (int tap = 0; tap < 9; tap++) {
-            const int tapn = tap < 8 ? tap + 1 : 8;
-#pragma unroll
-            for (int ks = 0; ks < 4; ks++) {                        // 4 K-steps of 32 channels = 2 weight stages
-                const int sl = ks >> 1, kk = ks & 1, cur = ks & 1;
-                const int g = layer * 18 + tap * 2 + sl;
-                if (kk == 1 && !(ABL & 2)) barrier_dma();          // stage st+1 has landed, nobody reads buffer sl any more
-#pragma unroll
-                for (int n = 0; n < 6; n++) {                        // pixel tile n: 4 MFMAs
-                    // activation fragment two tiles ahead (this K-step, or the next one's first two)
-                    const int tb = n + 2;
-                    if (ks == 3 && n == 0) { a0[0] = tap_addr1(0, tapn); a0[1] = tap_addr1(1, tapn); }
-                    if (tb < 6) {
-                        load_b1(fb[tb % 3], a0[tb], ks);
-                        if (ks == 3) a0[tb] = tap_addr1(tb, tapn);
-                    } else load_b1(fb[tb % 3], a0[tb - 6], ks < 3 ? ks + 1 : 0);
-                    // next K-step's weight fragments, one per tile; the refill of this buffer two stages ahead
-                    if (n < 4) {
-                        if (kk == 0) load_a1(fa[cur ^ 1][n], n, sl, 1);
-                        else {
-                            load_a1(fa[cur ^ 1][n], n, sl ^ 1, 0);
-                            if (!(ABL & 1)) stage_piece(g + 2 < nstages ? g + 2 : nstages - 1, sl, n);
-                        }
-                    }
-#pragma unroll
-                    for (int mt = 0; mt < 4; mt++)
-                        acc[mt][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[cur][mt], fb[n % 3], acc[mt][n], 0, 0, 0);
-                    // issue order inside the tile: reads, first MFMA, DMA piece, the other MFMAs
-                    if (n < 4) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                    else __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    if (kk == 1 && n < 4 && !(ABL & 1)) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
-                }
-            }
-        }
-        if (layer < 28) stamp(3 + 2 * layer);
-        // Round 2: the last stage barrier of a layer sits at the top of K-step 3 of tap 8,
-        // and this build still fetches that K-step's activation fragments of tiles 2..5 behind it, so without
-        // this barrier the partner wave of a board could start its in-place epilogue while those reads are
-        // in flight.  (k_tower16b closes the window structurally, without an extra barrier.)
-        __syncthreads();
-        if (layer & 1) epilogue(BIAS + ((layer + 1) & 1) * 512, yes{}, yes{});
-        else epilogue(BIAS + ((layer + 1) & 1) * 512, no{}, no{});
-        barrier_dma();
-        if (layer < 28) stamp(4 + 2 * layer);
-    }
-
-    // ---------------------------------------------------------------- heads (1x1, 128 -> 32 + 8)
-    {
-        const uint8_t *src = reinterpret_cast<const uint8_t *>(A.wh);     // [64][256 B], chunk ^ ((row & 7) << 1)
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int q0 = (wave * 4 + j) * 64, idx = q0 + lane, row = idx >> 4, cp = idx & 15;
-            dma16_abs(src + row * 256 + ((cp ^ ((row & 7) << 1)) * 16), q0 * 16);
-        }
-    }
-    f32x4 hacc[2][6];
-#pragma unroll
-    for (int m = 0; m < 2; m++)
-#pragma unroll
-        for (int nt = 0; nt < 6; nt++)
-#pragma unroll
-            for (int i = 0; i < 4; i++) hacc[m][nt][i] = 0.f;
-    barrier_dma();
-    const int nm = hc == 0 ? 2 : 1;                                  // policy: rows 0..31, value: rows 32..47
-#pragma unroll
-    for (int ks = 0; ks < 4; ks++) {
-        bf16x8 hb[6], ha[2];
-#pragma unroll
-        for (int nt = 0; nt < 6; nt++) {
-            const int p = nt * 16 + r16 < PIX ? nt * 16 + r16 : 0;
-            hb[nt] = lds_ld128(act_off + p * 256 + (((ks * 4 + q) ^ ((p & 7) << 1)) << 4));
-        }
-#pragma unroll
-        for (int m = 0; m < 2; m++) {
-            const int row = hc * 32 + m * 16 + r16;
-            ha[m] = lds_ld128(row * 256 + (((ks * 4 + q) ^ ((row & 7) << 1)) << 4));
-        }
-#pragma unroll
-        for (int m = 0; m < 2; m++)
-            if (m < nm)
-#pragma unroll
-                for (int nt = 0; nt < 6; nt++)
-                    hacc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ha[m], hb[nt], hacc[m][nt], 0, 0, 0);
-    }
-    stamp(60);
-    if (!board_ok) { stamp(61); return; }
-    uint8_t *Pb = reinterpret_cast<uint8_t *>(A.P) + (size_t)board * PIX * 64;
-    uint8_t *Vb = reinterpret_cast<uint8_t *>(A.V) + (size_t)board * PIX * 16;
-#pragma unroll
-    for (int m = 0; m < 2; m++) {
-        if (m >= nm) break;
-        const int c0 = hc * 32 + m * 16 + 4 * q;                     // head channel of element 0
-        const f32x4 b4 = *reinterpret_cast<const f32x4 *>(A.bh + c0);
-#pragma unroll
-        for (int nt = 0; nt < 6; nt++) {
-            const int p = nt * 16 + r16;
-            if (p < PIX && (hc == 0 || q < 2)) {                     // value head: channels 32..39 only
-                const float v0 = hacc[m][nt][0] + b4[0], v1 = hacc[m][nt][1] + b4[1];
-                const float v2 = hacc[m][nt][2] + b4[2], v3 = hacc[m][nt][3] + b4[3];
-                const uint2 pk = make_uint2(relu_bf16x2(pack_bf16x2(v0, v1)), relu_bf16x2(pack_bf16x2(v2, v3)));
-                if (hc == 0) *reinterpret_cast<uint2 *>(Pb + p * 64 + c0 * 2) = pk;
-                else *reinterpret_cast<uint2 *>(Vb + p * 16 + (c0 - 32) * 2) = pk;
-            }
-        }
-    }
-    stamp(61);
-}
-
-
-// ------------------------------------------------------------------------------------------
 // k_tower16b — the 16x16x32 trunk with its issue stream rebuilt around what k_tower16's ISA showed
 // (round 2; k_tower16 stays selectable for A/B runs).  Same workgroup, tile, LDS image, weight
 // stream and numerics contract; what changed, each aimed at a wave's speed when it has the SIMD
@@ -739,8 +434,11 @@ __global__ __launch_bounds__(NB * 128, 2) void k_tower16b(TowerArgs A)
     // (pixel & 7)): conflict-free stores (8 consecutive pixels -> 8 chunks of one 128-byte half) and fragment reads.
     // Without PAIR the stores are ds_write_b64 at chunk ^ ((pixel & 7) << 1), 4-way conflicts on the 32 store banks.
     auto chan_row = [&](int mt, int i) { return PAIR ? hc * 64 + (mt >> 1) * 32 + (i >> 2) * 8 + (mt & 1) * 4 + (i & 3) : hc * 64 + mt * 16 + i; };
+    int nrows = A.G;
+    if (A.n_rows) { const int n = *A.n_rows; nrows = n < A.G ? n : A.G; }
+    if ((int)blockIdx.x * NB >= nrows) return;     // compaction: no row for this workgroup (uniform, before any barrier / DMA)
     const int board = blockIdx.x * NB + wb_;
-    const bool board_ok = board < A.G;
+    const bool board_ok = board < nrows;
     const int act_off = ACT0 + wb_ * ACT_BYTES;
     const int r16 = lane & 15, q = lane >> 4;
 
@@ -759,7 +457,8 @@ __global__ __launch_bounds__(NB * 128, 2) void k_tower16b(TowerArgs A)
         if (piece < 36) dma16_abs(reinterpret_cast<const uint8_t *>(A.w1) + piece * 1024 + lane * 16, piece * 1024);
     }
     if (board_ok) {
-        const uint8_t *src = reinterpret_cast<const uint8_t *>(A.planes) + (size_t)board * PIX * 32;
+        const int srow = A.row_src ? A.row_src[board] : board;      // (wave-uniform: a scalar load)
+        const uint8_t *src = reinterpret_cast<const uint8_t *>(A.planes) + (size_t)srow * PIX * 32;
 #pragma unroll
         for (int j = 0; j < 2; j++) {
             const int q0 = (j * 2 + hc) * 64, idx = q0 + lane;
@@ -1616,104 +1315,67 @@ __global__ __launch_bounds__(512, 2) void k_tower16s(TowerArgs A)
 
 }  // namespace
 
-static int g_tower_variant = 36;    // 36 = k_tower16b<PAIR> with one filler per MFMA gap (default), 8 = the same with the fillers clustered, 2 = k_tower16b as first built (8-byte stores), 10 / 24 = k_tower16s without / with the 16-byte stores, 9 / 29 = 4 boards in lock-step, 3 / 33 = skip connection on the VALU, 1 = k_tower16, 0 = k_tower (32x32x16); 4..7, 11..20, 25, 30..32 = timing probes (XQ_TOWER_PROBES builds)
-// diagnostic switch (not part of the public ABI): both kernels compute the same function
+static int g_tower_variant = 36;    // 36 = k_tower16b<PAIR>, one filler per MFMA gap (default); 8 = the same with the fillers clustered; 0 = k_tower (32x32x16 comparison build); 24 / 29 = 4 boards per workgroup (k_tower16s staggered groups / lock-step); 11, 25, 30, 31 = timing probes (XQ_TOWER_PROBES builds, wrong results)
+// diagnostic switch (not part of the public ABI): the builds compute the same function
 extern "C" void xq_tower_set_variant(int v) { g_tower_variant = v; }
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property of a kernel: remembered per (kernel, device
+// ordinal) - a process may drive several GPUs (xq_config.device) - in one atomic bit mask per kernel
+template <auto KERNEL>
+static int tower_lds_opt_in(int bytes)
+{
+    static std::atomic<uint64_t> done{ 0 };
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return XQ_E_HIP;
+    if (done.load(std::memory_order_acquire) >> dev & 1) return 0;
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(KERNEL), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess)
+        return XQ_E_HIP;
+    done.fetch_or(1ull << dev, std::memory_order_release);
+    return 0;
+}
 
 template <bool STAMP>
 static int launch_tower(void *stream, const void *planes, const void *w1, const void *wt, const void *bias, const void *wh,
-                        const void *bh, void *policy_out, void *value_out, int n_boards, int n_blocks, void *stamps)
+                        const void *bh, void *policy_out, void *value_out, int n_boards, int n_blocks, void *stamps,
+                        const void *row_src, const void *n_rows)
 {
     if (!planes || !w1 || !bias || !wh || !bh || !policy_out || !value_out || n_boards <= 0 || n_blocks < 0 ||
         (n_blocks > 0 && !wt) || n_blocks > 64)
         return XQ_E_INVALID;
-    static bool attr_set = false;
-    if (!attr_set) {
-        for (const void *f : { reinterpret_cast<const void *>(&k_tower<STAMP>), reinterpret_cast<const void *>(&k_tower16<STAMP>),
-                               reinterpret_cast<const void *>(&k_tower16b<STAMP>), reinterpret_cast<const void *>(&k_tower16b<STAMP, 64>) })
-            if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) return XQ_E_HIP;
-#if XQ_TOWER_PROBES
-        if (STAMP)
-            for (const void *f : { reinterpret_cast<const void *>(&k_tower16<true, 1>), reinterpret_cast<const void *>(&k_tower16<true, 2>),
-                                   reinterpret_cast<const void *>(&k_tower16<true, 3>), reinterpret_cast<const void *>(&k_tower16<true, 4>),
-                                   reinterpret_cast<const void *>(&k_tower16b<true, 1>), reinterpret_cast<const void *>(&k_tower16b<true, 2>),
-                                   reinterpret_cast<const void *>(&k_tower16b<true, 4>), reinterpret_cast<const void *>(&k_tower16b<true, 8>),
-                                   reinterpret_cast<const void *>(&k_tower16b<true, 16>), reinterpret_cast<const void *>(&k_tower16b<true, 32>),
-                                   reinterpret_cast<const void *>(&k_tower16b<true, 5>), reinterpret_cast<const void *>(&k_tower16b<true, 64>) })
-                if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) return XQ_E_HIP;
-#endif
-        for (const void *f : { reinterpret_cast<const void *>(&k_tower16b<STAMP, 0, 2, true>), reinterpret_cast<const void *>(&k_tower16b<STAMP, 64, 2, true>),
-                               reinterpret_cast<const void *>(&k_tower16b<STAMP, 32, 2, true>) })
-            if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) return XQ_E_HIP;
-        for (const void *f : { reinterpret_cast<const void *>(&k_tower16s<STAMP>), reinterpret_cast<const void *>(&k_tower16s<STAMP, 0, true>) })
-            if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES4S) != hipSuccess) return XQ_E_HIP;
-#if XQ_TOWER_PROBES
-        if (STAMP)
-            for (const void *f : { reinterpret_cast<const void *>(&k_tower16b<true, 1, 2, true>), reinterpret_cast<const void *>(&k_tower16b<true, 2, 2, true>),
-                                   reinterpret_cast<const void *>(&k_tower16b<true, 32, 2, true>) })
-                if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) return XQ_E_HIP;
-        if (STAMP)
-            for (const void *f : { reinterpret_cast<const void *>(&k_tower16s<true, 1>), reinterpret_cast<const void *>(&k_tower16s<true, 2>), reinterpret_cast<const void *>(&k_tower16s<true, 2, true>) })
-                if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES4S) != hipSuccess) return XQ_E_HIP;
-#endif
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tower16b<STAMP, 0, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                LDS_BYTES4) != hipSuccess)
-            return XQ_E_HIP;
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tower16b<STAMP, 0, 4>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                LDS_BYTES4) != hipSuccess)
-            return XQ_E_HIP;
-        attr_set = true;
-    }
     TowerArgs a{ (const uint16_t *)planes, (const uint16_t *)w1, (const uint16_t *)wt, (const float *)bias,
                  (const uint16_t *)wh, (const float *)bh, (uint16_t *)policy_out, (uint16_t *)value_out, n_boards, n_blocks,
-                 (unsigned long long *)stamps };
-    const dim3 grid((n_boards + 1) / 2), blk(256);
+                 (unsigned long long *)stamps, (const int32_t *)row_src, (const int32_t *)n_rows };
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const dim3 grid2((n_boards + 1) / 2), grid4((n_boards + 3) / 4);
+#define XQ_TOWER_LAUNCH(KERNEL, GRID, THREADS, LDS)                                                     \
+    do {                                                                                                \
+        if (int rc = tower_lds_opt_in<&KERNEL>(LDS)) return rc;                                         \
+        hipLaunchKernelGGL((KERNEL), GRID, dim3(THREADS), LDS, st, a);                                  \
+    } while (0)
     const int v = g_tower_variant;
-    if (STAMP && v >= 4 && v != 8 && v != 9 && v != 10 && v != 24 && v != 29 && v != 33 && v != 36) {        // ablation builds (wrong results, timing only) ride on the stamp entry point
+    if ((row_src || n_rows) && v != 36 && v != 8 && v != 0) return XQ_E_INVALID;   // the experiments take no row map
+    if (v == 36) XQ_TOWER_LAUNCH((k_tower16b<STAMP, 32, 2, true>), grid2, 256, LDS_BYTES);
+    else if (v == 8) XQ_TOWER_LAUNCH((k_tower16b<STAMP, 0, 2, true>), grid2, 256, LDS_BYTES);
+    else if (v == 0) XQ_TOWER_LAUNCH((k_tower<STAMP>), grid2, 256, LDS_BYTES);
+    else if (v == 24) XQ_TOWER_LAUNCH((k_tower16s<STAMP, 0, true>), grid4, 512, LDS_BYTES4S);
+    else if (v == 29) XQ_TOWER_LAUNCH((k_tower16b<STAMP, 0, 4, true>), grid4, 512, LDS_BYTES4);
 #if XQ_TOWER_PROBES
-        if (v == 30) hipLaunchKernelGGL((k_tower16b<true, 1, 2, true>), grid, blk, LDS_BYTES, st, a);       // k_tower16b<PAIR>: no refills
-        else if (v == 31) hipLaunchKernelGGL((k_tower16b<true, 2, 2, true>), grid, blk, LDS_BYTES, st, a);  //                   no stage barriers
-        else if (v == 32) hipLaunchKernelGGL((k_tower16b<true, 32, 2, true>), grid, blk, LDS_BYTES, st, a); //                   one filler per MFMA gap (results valid)
-        else if (v == 25) hipLaunchKernelGGL((k_tower16s<true, 2, true>), dim3((n_boards + 3) / 4), dim3(512), LDS_BYTES4S, st, a);   // 16-byte stores + s_setprio 3 in epilogues
-        else if (v == 20) hipLaunchKernelGGL((k_tower16s<true, 2>), dim3((n_boards + 3) / 4), dim3(512), LDS_BYTES4S, st, a);   // k_tower16s: s_setprio 3 in epilogues (results valid)
-        else if (v == 11) hipLaunchKernelGGL((k_tower16s<true, 1>), dim3((n_boards + 3) / 4), dim3(512), LDS_BYTES4S, st, a);   // k_tower16s: 23 of 24 pixel tiles (power probe)
-        else if (v == 7) hipLaunchKernelGGL((k_tower16<true, 1>), grid, blk, LDS_BYTES, st, a);          // k_tower16: no refills
-        else if (v == 4) hipLaunchKernelGGL((k_tower16<true, 2>), grid, blk, LDS_BYTES, st, a);     //            no stage barriers
-        else if (v == 5) hipLaunchKernelGGL((k_tower16<true, 3>), grid, blk, LDS_BYTES, st, a);     //            neither
-        else if (v == 6) hipLaunchKernelGGL((k_tower16<true, 4>), grid, blk, LDS_BYTES, st, a);     //            no tap arithmetic
-        else if (v == 12) hipLaunchKernelGGL((k_tower16b<true, 1>), grid, blk, LDS_BYTES, st, a);   // k_tower16b: no refills
-        else if (v == 13) hipLaunchKernelGGL((k_tower16b<true, 2>), grid, blk, LDS_BYTES, st, a);   //             no stage barriers
-        else if (v == 14) hipLaunchKernelGGL((k_tower16b<true, 4>), grid, blk, LDS_BYTES, st, a);   //             no tap arithmetic
-        else if (v == 15) hipLaunchKernelGGL((k_tower16b<true, 8>), grid, blk, LDS_BYTES, st, a);   //             refills never waited for
-        else if (v == 16) hipLaunchKernelGGL((k_tower16b<true, 16>), grid, blk, LDS_BYTES, st, a);  // option: s_setprio 3 in epilogues
-        else if (v == 17) hipLaunchKernelGGL((k_tower16b<true, 32>), grid, blk, LDS_BYTES, st, a);  // option: one filler per MFMA gap
-        else if (v == 18) hipLaunchKernelGGL((k_tower16b<true, 5>), grid, blk, LDS_BYTES, st, a);   // no refills, no tap arithmetic
-        else if (v == 19) hipLaunchKernelGGL((k_tower16b<true, 64>), grid, blk, LDS_BYTES, st, a);  // comparison: skip connection on the VALU (the form before)
-        else return XQ_E_INVALID;
-#else
-        return XQ_E_INVALID;      // timing probes are compiled with -DXQ_TOWER_PROBES=1 only (XQ_TOWER_PROBES=1 in the environment of _lib.build)
+    else if (STAMP && v == 30) XQ_TOWER_LAUNCH((k_tower16b<true, 1, 2, true>), grid2, 256, LDS_BYTES);   // no weight refills
+    else if (STAMP && v == 31) XQ_TOWER_LAUNCH((k_tower16b<true, 2, 2, true>), grid2, 256, LDS_BYTES);   // no stage barriers
+    else if (STAMP && v == 25) XQ_TOWER_LAUNCH((k_tower16s<true, 2, true>), grid4, 512, LDS_BYTES4S);    // s_setprio 3 in epilogues
+    else if (STAMP && v == 11) XQ_TOWER_LAUNCH((k_tower16s<true, 1, true>), grid4, 512, LDS_BYTES4S);    // 23 of 24 pixel tiles (power probe)
 #endif
-    } else if (v == 2) hipLaunchKernelGGL(k_tower16b<STAMP>, grid, blk, LDS_BYTES, st, a);
-    else if (v == 3) hipLaunchKernelGGL((k_tower16b<STAMP, 64>), grid, blk, LDS_BYTES, st, a);
-    else if (v == 36) hipLaunchKernelGGL((k_tower16b<STAMP, 32, 2, true>), grid, blk, LDS_BYTES, st, a);  // k_tower16b<PAIR> with one filler per MFMA gap
-    else if (v == 33) hipLaunchKernelGGL((k_tower16b<STAMP, 64, 2, true>), grid, blk, LDS_BYTES, st, a);  // k_tower16b<PAIR> with the skip connection on the VALU
-    else if (v == 8) hipLaunchKernelGGL((k_tower16b<STAMP, 0, 2, true>), grid, blk, LDS_BYTES, st, a);   // k_tower16b + 16-byte epilogue stores
-    else if (v == 24) hipLaunchKernelGGL((k_tower16s<STAMP, 0, true>), dim3((n_boards + 3) / 4), dim3(512), LDS_BYTES4S, st, a);   // + 16-byte epilogue stores, conflict-free
-    else if (v == 10) hipLaunchKernelGGL(k_tower16s<STAMP>, dim3((n_boards + 3) / 4), dim3(512), LDS_BYTES4S, st, a);   // 4 boards, two groups two stage steps apart
-    else if (v == 29) hipLaunchKernelGGL((k_tower16b<STAMP, 0, 4, true>), dim3((n_boards + 3) / 4), dim3(512), LDS_BYTES4, st, a);   // 4 boards in lock-step + 16-byte epilogue stores
-    else if (v == 9) hipLaunchKernelGGL((k_tower16b<STAMP, 0, 4>), dim3((n_boards + 3) / 4), dim3(512), LDS_BYTES4, st, a);   // 4 boards share one weight stream
-    else if (v == 1) hipLaunchKernelGGL(k_tower16<STAMP>, grid, blk, LDS_BYTES, st, a);
-    else if (v == 0) hipLaunchKernelGGL(k_tower<STAMP>, grid, blk, LDS_BYTES, st, a);
     else return XQ_E_INVALID;
+#undef XQ_TOWER_LAUNCH
     return hipGetLastError() == hipSuccess ? 0 : XQ_E_HIP;
 }
 
 extern "C" int xq_tower_nhwc_bf16(void *stream, const void *planes, const void *w1, const void *wt, const void *bias,
                                   const void *wh, const void *bh, void *policy_out, void *value_out, int n_boards,
-                                  int n_blocks)
+                                  int n_blocks, const void *row_src_dev, const void *n_rows_dev)
 {
-    return launch_tower<false>(stream, planes, w1, wt, bias, wh, bh, policy_out, value_out, n_boards, n_blocks, nullptr);
+    return launch_tower<false>(stream, planes, w1, wt, bias, wh, bh, policy_out, value_out, n_boards, n_blocks, nullptr,
+                               row_src_dev, n_rows_dev);
 }
 
 // diagnostic only (not part of the public ABI): s_memtime phase stamps, 64 u64 per workgroup
@@ -1724,7 +1386,8 @@ extern "C" int xq_tower_debug_stamps(void *stream, const void *planes, const voi
                                      int n_blocks, void *stamps)
 {
     if (!stamps) return XQ_E_INVALID;
-    return launch_tower<true>(stream, planes, w1, wt, bias, wh, bh, policy_out, value_out, n_boards, n_blocks, stamps);
+    return launch_tower<true>(stream, planes, w1, wt, bias, wh, bh, policy_out, value_out, n_boards, n_blocks, stamps,
+                              nullptr, nullptr);
 }
 
 // diagnostic only: what the matrix pipes sustain under this board's power cap — 2 waves per SIMD

@@ -1,5 +1,6 @@
 """Multi-GPU self-play: games shard across ranks, one process per GPU, no exchange during play;
-one RCCL all-gather of fixed-size sample records at the end of the epoch.
+one RCCL all-gather of fixed-size sample records at the end of the epoch, one broadcast of the weights at its
+start.
 
 The reference's only parallelism is a 4-process pool with pickled results
 (self_play.py:368-469); here `torch.distributed` (backend "nccl" = RCCL over xGMI, "gloo" in the
@@ -112,12 +113,58 @@ def record_to_sample(rec, temperature=1.0):
     return unpack_board(rec["board"]), {m: p for m, p in zip(moves, probs)}, float(rec["z"])
 
 
-def play_sharded(make_evaluator, num_games, sims, base_seed=0, temperature=1.0, group=None, gather=True):
+def broadcast_weights(net_or_state_dict, src=0, group=None, device=None):
+    """Every rank ends up with rank `src`'s weights, bit for bit: the counterpart of the reference shipping the
+    state_dict to every worker with its task (self_play.py:386,394, rebuilt at :337-339) - here once per epoch
+    instead of once per game.  All floating-point tensors of the state_dict (parameters and BatchNorm statistics,
+    in state_dict order) travel as ONE flat float32 buffer (24.6 M values = 98.5 MB for the reference net; fp32
+    because InferenceNet folds BatchNorm from the fp32 values), integer buffers (num_batches_tracked) as one flat
+    int64 buffer: two broadcasts in all.  Tensors are overwritten in place; a leaf evaluator must be (re)built
+    from them afterwards (InferenceNet folds and re-lays the weights when it is constructed).
+    `device`: where the flat buffers live - default "cuda" under nccl (RCCL), "cpu" under gloo.
+    Returns the number of bytes broadcast."""
+    import torch
+    import torch.distributed as dist
+    sd = net_or_state_dict.state_dict() if hasattr(net_or_state_dict, "state_dict") else net_or_state_dict
+    if device is None:
+        device = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+    fl = [t for t in sd.values() if torch.is_tensor(t) and t.is_floating_point()]
+    it = [t for t in sd.values() if torch.is_tensor(t) and not t.is_floating_point()]
+    # every rank must hold the same architecture: compare the layout before any payload moves
+    sig = torch.tensor([len(fl), sum(t.numel() for t in fl), len(it), sum(t.numel() for t in it)], dtype=torch.int64, device=device)
+    ref = sig.clone()
+    dist.broadcast(ref, src, group=group)
+    ok = torch.tensor([1 if torch.equal(ref, sig) else 0], dtype=torch.int64, device=device)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)     # every rank raises, or none: nobody is left in a broadcast
+    if int(ok.item()) == 0:
+        raise ValueError("broadcast_weights: state_dict layouts differ between ranks (this rank %s, rank %d %s)"
+                         % (sig.tolist(), src, ref.tolist()))
+    nbytes = 0
+    for tensors, dtype in ((fl, torch.float32), (it, torch.int64)):
+        if not tensors:
+            continue
+        flat = torch.cat([t.detach().reshape(-1).to(device=device, dtype=dtype) for t in tensors])
+        dist.broadcast(flat, src, group=group)
+        nbytes += flat.numel() * flat.element_size()
+        off = 0
+        with torch.no_grad():
+            for t in tensors:
+                n = t.numel()
+                t.copy_(flat[off:off + n].view(t.shape).to(dtype=t.dtype))
+                off += n
+    return nbytes
+
+
+def play_sharded(make_evaluator, num_games, sims, base_seed=0, temperature=1.0, group=None, gather=True, network=None):
     """Each rank plays its shard on its own GPU, then all ranks all-gather the sample records.
+    `network` (a ChessNet on this rank's GPU): rank 0's weights are broadcast to every rank first
+    (broadcast_weights: what parallel_self_play's per-task state_dict does, self_play.py:386-394) and every rank
+    builds its leaf evaluator from them; `make_evaluator` may then be None.  Without `network` the caller's
+    `make_evaluator()` is trusted to produce identical evaluators on all ranks.
     Returns (engine results of the local shard, gathered uint8 tensor or None)."""
     import torch
     import torch.distributed as dist
-    from .engine import SelfPlayEngine
+    from .engine import SelfPlayEngine, TorchNetEvaluator
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     if num_games < world:
         # every rank sees the same arguments, so every rank raises: nobody is left waiting in the all-gather
@@ -126,7 +173,11 @@ def play_sharded(make_evaluator, num_games, sims, base_seed=0, temperature=1.0, 
     lo, hi = shard_range(num_games, rank, world)
     n_local = hi - lo
     n_pad = shard_range(num_games, 0, world)[1]               # largest shard
-    ev = make_evaluator()
+    if network is not None:
+        broadcast_weights(network, src=0, group=group)
+        ev = make_evaluator() if make_evaluator is not None else TorchNetEvaluator(network)
+    else:
+        ev = make_evaluator()
     eng = SelfPlayEngine(n_local, sims=sims, temperature=temperature,
                          planes_format=getattr(ev, "planes_format", _lib.PLANES_NONE),
                          device=torch.cuda.current_device(),

@@ -21,6 +21,7 @@ from .chess_env import decode_move, format_end_reason
 class HashNetEvaluator:
     """SURVEY.md Appendix B evaluator, on the GPU."""
     planes_format = _lib.PLANES_NONE
+    deterministic = True            # same position -> same priors, whatever the row: root evaluations may be carried over
 
     def __init__(self, salt=0):
         self.salt = salt
@@ -41,6 +42,7 @@ class CallbackEvaluator:
     [(dict move->prior, value)] (neural_network.py:96-126).  Rows are passed with the same
     multiplicity the reference passes them (self_play.py:139-143)."""
     planes_format = _lib.PLANES_NONE
+    deterministic = False           # a caller's network may be stochastic: every root is evaluated afresh, as the reference does
 
     def __init__(self, network):
         self.network = network
@@ -77,7 +79,10 @@ class CallbackEvaluator:
 
 
 class TorchNetEvaluator:
-    """InferenceNet under PyTorch-ROCm; the search kernel writes its input planes in place."""
+    """InferenceNet under PyTorch-ROCm; the search kernel writes its input planes in place.  On the hand-written
+    single-launch path the evaluator runs with row compaction: only slots with a pending leaf are network rows
+    (SelfPlayEngine.set_row_compaction)."""
+    deterministic = True
 
     def __init__(self, net, dtype=None, channels_last=True, chunk=None, policy_columns="reachable", fused_tower=True):
         import torch
@@ -100,9 +105,13 @@ class TorchNetEvaluator:
             fused_tower=fused_tower, allow_library_fallback=(dtype != torch.bfloat16 or not channels_last))
         self.chunk = chunk
         self.kind = _lib.EVAL_LOGITS_BF16 if dtype == torch.bfloat16 else _lib.EVAL_LOGITS_F32
+        self.row_compaction = bool(self.inet.supports_row_map and not chunk)
+        self.row_src = self.n_rows_dev = None
 
     def bind(self, engine):
         torch = self.torch
+        engine.set_row_compaction(self.row_compaction)
+        self.row_src, self.n_rows_dev = engine.row_map()
         G = engine.n_rows                                       # one row per pending-leaf slot
         if self.channels_last:
             self.storage = torch.zeros((G, 10, 9, 16), dtype=self.dtype, device="cuda")
@@ -121,6 +130,9 @@ class TorchNetEvaluator:
 
     def evaluate(self, engine):
         G = engine.n_rows
+        if self.row_compaction:
+            self.inet(self.x, out_logits=self.logits, out_values=self.values, row_src=self.row_src, n_rows=self.n_rows_dev)
+            return self.kind, self.logits.data_ptr(), self.values.data_ptr()
         step = self.chunk or G
         for s in range(0, G, step):
             self.inet(self.x[s:s + step], out_logits=self.logits[s:s + step], out_values=self.values[s:s + step])
@@ -187,6 +199,13 @@ class SelfPlayEngine:
         self.priors_ptr = self.L.xq_engine_priors_ptr(h)
         self.values_ptr = self.L.xq_engine_values_ptr(h)
         self.n_rows = n_games                                   # evaluator rows: n_games * leaf slots
+        # root evaluation carry-over: None = automatic (on whenever it is result-identical: one deterministic
+        # evaluator, no noise / virtual loss / tree reuse / arena mode), True / False = the caller's choice
+        self.root_eval_carry = None
+        self._carry_on = False
+        self.row_compaction = False
+        self._noise = self._vloss = False
+        self.tree_reuse = False
         if stream is not None:
             _lib.check(self.L.xq_engine_set_stream(h, C.c_void_p(stream)))
         if temperature >= 0.01 and temperature != 1.0:
@@ -223,11 +242,60 @@ class SelfPlayEngine:
         _lib.check(self.L.xq_engine_set_roots(self.h, _lib.ptr(boards), _lib.ptr(states)))
 
     def set_root_eval_carry(self, enable=True):
-        """Opt-in, result-identical: the played child's network evaluation becomes the next root's instead of being
-        computed a second time (the reference rebuilds its tree every ply, self_play.py:98); round 0 of a ply — tree
-        kernel and network forward — is then skipped whenever no game needs it.  Call before new games start."""
+        """Result-identical work elimination: the played child's network evaluation becomes the next root's instead
+        of being computed a second time (the reference rebuilds its tree every ply, self_play.py:98), so round 0 of
+        a ply has nothing to evaluate.  play() / play_refill() switch it on by themselves whenever it is
+        result-identical (one deterministic evaluator, no root noise / virtual loss / tree reuse / arena mode);
+        this call fixes the choice: True insists (and raises for a combination it cannot serve), False evaluates
+        every root afresh like the reference.  None returns to automatic.  Call before new games start."""
+        if enable is None:
+            self.root_eval_carry = None
+            return
         _lib.check(self.L.xq_engine_set_root_eval_carry(self.h, 1 if enable else 0))
-        self.root_eval_carry = bool(enable)
+        self.root_eval_carry = self._carry_on = bool(enable)
+
+    def _auto_carry(self, evaluator, opponent_evaluator):
+        """Decide the carry-over for the games about to start (play / play_refill)."""
+        if self.root_eval_carry is not None:
+            if self.root_eval_carry and opponent_evaluator is not None:
+                raise _lib.XqError("root evaluation carry-over needs one network for both sides (the carried priors are the mover's network's)")
+            return self._carry_on
+        want = bool(getattr(evaluator, "deterministic", False) and opponent_evaluator is None and not self.opponent_mode
+                    and not self._noise and not self._vloss and not self.tree_reuse)
+        if want != self._carry_on:
+            _lib.check(self.L.xq_engine_set_root_eval_carry(self.h, 1 if want else 0))
+            self._carry_on = want
+        return want
+
+    def _drop_auto_carry(self):
+        # an extension is being switched on: the automatic carry-over steps aside (an explicit one refuses in C)
+        if self._carry_on and self.root_eval_carry is None:
+            _lib.check(self.L.xq_engine_set_root_eval_carry(self.h, 0))
+            self._carry_on = False
+
+    def set_row_compaction(self, enable=True):
+        """Only slots with a pending leaf become evaluator rows (xq_engine_set_row_compaction); evaluators whose
+        kernels take the row map switch it on when they are bound (TorchNetEvaluator on the hand-written path)."""
+        _lib.check(self.L.xq_engine_set_row_compaction(self.h, 1 if enable else 0))
+        self.row_compaction = bool(enable)
+
+    def row_map(self):
+        """(row_src, row_count) device pointers as ints, or (None, None) without compaction."""
+        a, b = C.c_void_p(), C.c_void_p()
+        _lib.check(self.L.xq_engine_row_map(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def row_history(self, cap=65536, reset=False):
+        """Rows the evaluator had to run in each of the last `cap` search rounds (oldest first), rounds launched."""
+        rows = np.zeros(cap, np.int32)
+        n = C.c_int64()
+        _lib.check(self.L.xq_engine_read_row_history(self.h, _lib.ptr(rows), cap, C.byref(n), 1 if reset else 0))
+        return rows[:min(cap, n.value)], n.value
+
+    def leaf_rows(self):
+        rows = np.zeros(self.n_rows, np.int32)
+        _lib.check(self.L.xq_engine_read_leaf_rows(self.h, _lib.ptr(rows)))
+        return rows
 
     def roots_not_ready(self):
         n = np.zeros(1, np.int32)
@@ -236,7 +304,8 @@ class SelfPlayEngine:
 
     def search(self, evaluator, skip_round0=False):
         """One MCTS.search for every game (self_play.py:89-154); root visits are final after it.
-        skip_round0: every root already holds its expansion (set_root_eval_carry + roots_not_ready() == 0)."""
+        skip_round0: every root already holds its expansion (set_root_eval_carry + roots_not_ready() == 0); with row
+        compaction nobody needs to know: a carried root simply has no row in round 0."""
         kind, a, v = _lib.EVAL_PRIORS, None, None
         if skip_round0:
             a, v = self.priors_ptr, self.values_ptr          # nothing is pending: round 1 has nothing to consume
@@ -264,17 +333,22 @@ class SelfPlayEngine:
         """Per-ply temperature (extension; the reference uses one temperature per game)."""
         tab = None
         if temperature >= 0.01 and temperature != 1.0:
-            top = 65536 if getattr(self, "tree_reuse", False) else self.sims + 1     # carried visits exceed sims
+            top = 65536 if self.tree_reuse else self.sims + 1                        # carried visits exceed sims
             tab = np.ascontiguousarray(np.arange(top, dtype=np.int64) ** (1.0 / temperature), dtype=np.float64)
         _lib.check(self.L.xq_engine_set_temperature(self.h, float(temperature), _lib.ptr(tab), 0 if tab is None else len(tab)))
 
     def set_root_noise(self, alpha, epsilon, seed=0):
         """Dirichlet root noise (extension, BASELINE C5): root priors (1-eps) P + eps Dir(alpha)."""
+        if epsilon > 0:
+            self._drop_auto_carry()
         _lib.check(self.L.xq_engine_set_root_noise(self.h, float(alpha), float(epsilon), int(seed)))
+        self._noise = epsilon > 0
 
     def set_tree_reuse(self, enable=True):
         """Keep the played move's subtree as the next ply's tree (extension; the reference builds a
         fresh tree every ply).  Call before new games are started."""
+        if enable:
+            self._drop_auto_carry()
         _lib.check(self.L.xq_engine_set_tree_reuse(self.h, 1 if enable else 0))
         self.tree_reuse = bool(enable)
         self.set_temperature(self.temperature)             # counts ** (1/T) table must cover carried visits
@@ -284,7 +358,10 @@ class SelfPlayEngine:
         (extension; the reference's rounds all reach one leaf).  The evaluator then works on
         n_rows = n_games * leaf_batch rows.  Call before new games are started and before an
         evaluator is bound."""
+        if enable:
+            self._drop_auto_carry()
         _lib.check(self.L.xq_engine_set_virtual_loss(self.h, 1 if enable else 0))
+        self._vloss = bool(enable)
         self.n_rows = self.n_games * self.L.xq_engine_leaf_slots(self.h)
         self.priors_ptr = self.L.xq_engine_priors_ptr(self.h)
         self.values_ptr = self.L.xq_engine_values_ptr(self.h)
@@ -307,6 +384,7 @@ class SelfPlayEngine:
         """Play G games to the end (self_play_game for every game).  `seeds[g]` seeds game g's
         MT19937 stream like np.random.seed; `uniforms` overrides the streams.
         `temperature_schedule(ply) -> T` (extension) overrides the constant temperature per ply."""
+        carry = self._auto_carry(evaluator, opponent_evaluator)
         evaluator.bind(self)
         if opponent_evaluator is not None:
             opponent_evaluator.bind(self)
@@ -315,9 +393,6 @@ class SelfPlayEngine:
             self.set_uniforms(uniforms)
         self.ply_temperature = []
         cur_t = None
-        carry = getattr(self, "root_eval_carry", False)
-        if carry and opponent_evaluator is not None:
-            raise _lib.XqError("root evaluation carry-over needs one network for both sides (the carried priors are the mover's network's)")
         skip0 = False
         for ply in range(min(self.max_moves, _lib.MAX_PLIES)):
             t = self.temperature if temperature_schedule is None else float(temperature_schedule(ply))
@@ -328,7 +403,7 @@ class SelfPlayEngine:
             ev = evaluator if (ply % 2 == 0 or opponent_evaluator is None) else opponent_evaluator   # self_play.py:211
             self.search(ev, skip_round0=skip0)
             _lib.check(self.L.xq_engine_play_move(self.h))
-            skip0 = carry and self.roots_not_ready() == 0
+            skip0 = carry and not self.row_compaction and self.roots_not_ready() == 0
             if check_every and ply % check_every == check_every - 1 and self.active_games() == 0:
                 break
         _lib.check(self.L.xq_engine_finalize(self.h))
@@ -341,19 +416,19 @@ class SelfPlayEngine:
         by game id.  Returns the per-game outcome arrays (by game id) and the number of plies stepped."""
         seeds = np.ascontiguousarray(seeds, dtype=np.uint32)
         total = len(seeds)
+        carry = self._auto_carry(evaluator, None)
         evaluator.bind(self)
         _lib.check(self.L.xq_engine_refill_begin(self.h, _lib.ptr(seeds), total))
         active = np.zeros(1, np.int32)
         plies = 0
         cap = max_plies or (total // self.n_games + 2) * _lib.MAX_PLIES + 8
-        carry = getattr(self, "root_eval_carry", False)
         skip0 = False
         while plies < cap:
             self.search(evaluator, skip_round0=skip0)
             _lib.check(self.L.xq_engine_play_move(self.h))
             poll = plies % check_every == check_every - 1
             _lib.check(self.L.xq_engine_refill_step(self.h, C.c_void_p(records_ptr), _lib.ptr(active) if poll else None))
-            skip0 = carry and self.roots_not_ready() == 0        # (after the refill: restarted slots need their round 0)
+            skip0 = carry and not self.row_compaction and self.roots_not_ready() == 0   # (after the refill: restarted slots need their round 0)
             plies += 1
             if poll and int(active[0]) == 0:
                 break

@@ -166,7 +166,16 @@ class InferenceNet(nn.Module):
 
     Input : planes tensor the search kernel wrote — logical shape [G, C_in, 10, 9] with
             C_in = 15 (NCHW) or 16 (channels-last storage, channel 15 zero).
-    Output: (logits [G, 8100], values [G]) in `dtype`.
+    Output: (logits [G, n_policy], values [G]) in `dtype`.  With the default policy_columns="reachable" the
+            logits are NOT in the reference's from*90+to order: n_policy = 2,304 compact columns (2,294 real ones,
+            padded), and `column_map[from*90+to]` gives a move's column (-1: never legal).  policy_columns="all"
+            keeps the reference's 8,100 columns in order (padded to 8,256 on the hand-written path).  Callers that
+            index logits by move must go through column_map (the engine does: xq_engine_set_logit_columns).
+
+    The hand-written kernels cover dtype=bfloat16, c_in=16 (channels-last), 128 channels on a CUDA device; any
+    other configuration raises ValueError unless allow_library_fallback=True asks for PyTorch's library kernels.
+    row_src / n_rows (device pointers from SelfPlayEngine.row_map(), hand-written fused path only): evaluator row
+    compaction - row r reads the planes of x[row_src[r]], writes outputs to row r, rows >= *n_rows are skipped.
     """
 
     def __init__(self, net, dtype=torch.bfloat16, c_in=16, device="cuda", policy_columns="reachable", fused_tower=True,
@@ -205,6 +214,8 @@ class InferenceNet(nn.Module):
         self._buf = None
         self._hbuf = None
         self.tower_events = None
+        # evaluator row compaction needs the row map inside the kernels: the single-launch hand-written path only
+        self.supports_row_map = bool(self.use_hip_conv and fused_tower)
         if self.use_hip_conv:
             self.hip_w = [w.permute(2, 3, 0, 1).reshape(9, w.shape[0], w.shape[1]).to(device=device, dtype=dtype).contiguous()
                           for w, _ in convs]
@@ -304,7 +315,7 @@ class InferenceNet(nn.Module):
             self._hbuf = (torch.empty((g, 2880), dtype=torch.bfloat16, device=device), flat[:g * 720].view(g, 720), flat)
         return self._hbuf[0], self._hbuf[1]
 
-    def trunk_hip(self, x):
+    def trunk_hip(self, x, row_src=None, n_rows=None):
         """planes -> (policy-head activations [G, 2880], value-head activations [G, 720]) in one
         launch of k_tower: activations stay in LDS across all layers."""
         from . import _lib
@@ -319,17 +330,19 @@ class InferenceNet(nn.Module):
         _lib.check(_lib.lib().xq_tower_nhwc_bf16(torch.cuda.current_stream().cuda_stream, xin.data_ptr(),
                                                  self.hip_w[0].data_ptr(), self.hip_wt.data_ptr(), self.hip_bt.data_ptr(),
                                                  self.hip_hw.data_ptr(), self.hip_hb.data_ptr(), hp.data_ptr(),
-                                                 hv.data_ptr(), g, self.n_blocks))
+                                                 hv.data_ptr(), g, self.n_blocks, row_src, n_rows))
         if ev is not None:
             ev[1].record()
             self.tower_events.append(ev)
         return hp, hv
 
     @torch.no_grad()
-    def forward(self, x, out_logits=None, out_values=None):
+    def forward(self, x, out_logits=None, out_values=None, row_src=None, n_rows=None):
         if self.use_hip_conv and x.is_cuda and self.fused_tower:
-            hp, hv = self.trunk_hip(x)
-            return self._fc(hp, hv, x.shape[0], out_logits, out_values)
+            hp, hv = self.trunk_hip(x, row_src, n_rows)
+            return self._fc(hp, hv, x.shape[0], out_logits, out_values, n_rows)
+        if row_src is not None or n_rows is not None:
+            raise ValueError("InferenceNet: a row map needs the single-launch hand-written path (supports_row_map)")
         if self.use_hip_conv and x.is_cuda:
             x = self._tower_hip(x)
         else:
@@ -355,7 +368,7 @@ class InferenceNet(nn.Module):
             hv = h[..., 32:].reshape(g, 720)
         return self._fc(hp, hv, g, out_logits, out_values)
 
-    def _fc(self, hp, hv, g, out_logits, out_values):
+    def _fc(self, hp, hv, g, out_logits, out_values, n_rows=None):
         if self.use_hip_conv and hp.is_cuda:
             # hand-written FC kernels (csrc/xq_policy.hip): fixed accumulation order, no library GEMM
             from . import _lib
@@ -368,9 +381,10 @@ class InferenceNet(nn.Module):
             assert out_logits.is_contiguous() and out_logits.shape == (g, self.n_policy) and out_logits.dtype == torch.bfloat16
             assert hp.is_contiguous() and hv.is_contiguous() and out_values.is_contiguous()
             _lib.check(L.xq_policy_fc_bf16(st, hp.data_ptr(), self.pfw.data_ptr(), self.hip_pfb.data_ptr(),
-                                           out_logits.data_ptr(), g, self.n_policy, 2880))
+                                           out_logits.data_ptr(), g, self.n_policy, 2880, n_rows))
             _lib.check(L.xq_value_head_bf16(st, hv.data_ptr(), self.hip_v1w.data_ptr(), self.hip_v1b.data_ptr(),
-                                            self.hip_v2w.data_ptr(), self.hip_v2b.data_ptr(), out_values.data_ptr(), g))
+                                            self.hip_v2w.data_ptr(), self.hip_v2b.data_ptr(), out_values.data_ptr(), g,
+                                            n_rows))
             return out_logits, out_values
         if out_logits is not None:
             policy = torch.addmm(self.pfb, hp, self.pfw.t(), out=out_logits)   # no extra copy of the logits

@@ -248,15 +248,33 @@ typedef struct {
 } xq_sample_record;
 int  xq_engine_pack_samples(xq_engine *e, void *records_dev /* xq_sample_record[G][70] */);
 
-/* Opt-in, result-identical work elimination (default off; the reference has no counterpart: it rebuilds its tree
+/* Result-identical work elimination (off until asked for; the reference has no counterpart: it rebuilds its tree
  * every ply, self_play.py:98, and so evaluates every new root a second time).  With it on, xq_engine_play_move
  * carries the played child's network evaluation over as the next root's and leaves the tree as round 0 would
- * (root.visit_count = first batch size, children unvisited); the caller may then skip round 0 — tree kernel and
- * network forward — of a ply whenever xq_engine_roots_not_ready reports 0 games needing it (fresh games always
- * need it).  Games, visit counts, pi and z are bit-identical to the default path with a deterministic evaluator.
- * Not combinable with tree reuse, virtual loss or root noise; call before xq_engine_new_games. */
+ * (root.visit_count = first batch size, children unvisited); round 0 of the next ply then has nothing to evaluate
+ * for that game.  With row compaction (below) the empty round costs no network time by itself; without it the
+ * caller may skip round 0 - tree kernel and network forward - of a ply whenever xq_engine_roots_not_ready reports
+ * 0 games needing it (fresh games always need it).  Games, visit counts, pi and z are bit-identical to the default
+ * path with a deterministic, row-independent evaluator.  Not combinable with tree reuse, virtual loss, root noise
+ * or opponent mode; call before xq_engine_new_games. */
 int  xq_engine_set_root_eval_carry(xq_engine *e, int enable);
 int  xq_engine_roots_not_ready(xq_engine *e, int32_t *n_host);
+
+/* Evaluator row compaction (off until asked for: row = slot, every slot is evaluated, what the reference does with
+ * its per-game batches, self_play.py:139-143).  When on, every xq_engine_search_round is followed by a numbering of
+ * the slots that hold a pending leaf, in slot order: the evaluator reads the planes of row r at slot row_src[r],
+ * writes logits / value to row r and stops at *row_count rows; consume reads a leaf's outputs from its row.
+ * xq_engine_row_map hands out the two DEVICE pointers (NULL while compaction is off); xq_tower_nhwc_bf16,
+ * xq_policy_fc_bf16 and xq_value_head_bf16 take them.  Games that are over, rounds that ended on terminal leaves,
+ * roots carried over (above) and empty virtual-loss slots then cost no network time, with no host round trip.
+ * Results do not depend on the numbering (every evaluator kernel is row-independent); evaluators that fill
+ * xq_engine_priors_ptr (XQ_EVAL_PRIORS) stay indexed by slot.
+ * xq_engine_read_row_history: rows of the last `cap` search rounds, oldest first, and the rounds launched since
+ * the count was last reset.  xq_engine_read_leaf_rows: row of every slot (-1 = no pending leaf). */
+int  xq_engine_set_row_compaction(xq_engine *e, int enable);
+int  xq_engine_row_map(xq_engine *e, const int32_t **row_src_dev, const int32_t **row_count_dev);
+int  xq_engine_read_row_history(xq_engine *e, int32_t *rows_host, int cap, int64_t *n_rounds, int reset);
+int  xq_engine_read_leaf_rows(xq_engine *e, int32_t *rows_host /* [G * leaf_slots] */);
 
 /* ---- refill: `total` games through the engine's G concurrent slots, a finished game's slot being restarted
  * on the next unplayed game at once — what the reference's pool does by construction (imap_unordered hands a
@@ -295,10 +313,12 @@ int  xq_heads_nhwc_bf16(void *hip_stream, const void *x_dev, const void *w_dev, 
  * bf16, bias float32 [1 + 2*n_blocks][128] (conv1 first), wh / bh as in xq_heads_nhwc_bf16;
  * outputs as xq_heads_nhwc_bf16.  Same arithmetic as the per-layer calls (bf16 storage between
  * layers, fp32 accumulation in the same order), except that the skip connection is added in fp32
- * before the single bf16 rounding of a block's output (one rounding fewer per block). */
+ * before the single bf16 rounding of a block's output (one rounding fewer per block).
+ * row_src_dev / n_rows_dev (both optional, device int32: xq_engine_row_map): board b reads planes row row_src[b],
+ * outputs go to row b, boards at or beyond *n_rows are skipped. */
 int  xq_tower_nhwc_bf16(void *hip_stream, const void *planes_dev, const void *w1_dev, const void *wt_dev,
                         const void *bias_dev, const void *wh_dev, const void *bh_dev, void *policy_out_dev,
-                        void *value_out_dev, int n_boards, int n_blocks);
+                        void *value_out_dev, int n_boards, int n_blocks, const void *row_src_dev, const void *n_rows_dev);
 
 /* The policy head's fully-connected layer (neural_network.py:39,64: nn.Linear(32*10*9, 8100) applied to the
  * flattened policy-conv activations): logits[m][n] = bias[n] + sum_k act[m][k] * w[n][k].
@@ -307,16 +327,18 @@ int  xq_tower_nhwc_bf16(void *hip_stream, const void *planes_dev, const void *w1
  * [n_rows][n_cols] bf16; all device pointers.  k % 64 == 0 and n_cols % 192 == 0 (pad w / bias with zero rows;
  * the caller may also DROP rows of w: the search gathers legal-move logits only, neural_network.py:148-169,
  * so a column no legal move can index is a dead output — see xq_engine_set_logit_columns).  fp32 accumulation
- * in a fixed order: results do not depend on the launch, the tile position or n_rows. */
+ * in a fixed order: results do not depend on the launch, the tile position or n_rows.
+ * n_rows_dev (optional, device int32: xq_engine_row_map): only rows below it are computed. */
 int  xq_policy_fc_bf16(void *hip_stream, const void *act_dev, const void *w_dev, const void *bias_dev, void *logits_dev,
-                       int n_rows, int n_cols, int k);
+                       int n_rows, int n_cols, int k, const void *n_rows_dev);
 
 /* The value head behind its 1x1 convolution (neural_network.py:43-45,66-69): values[m] = tanh(fc2(relu(fc1(hv[m])))).
  * hv [n_rows][720] bf16 ((h, w, c) order, as xq_tower_nhwc_bf16 writes it) with at least 32 readable bytes behind
  * the last row; w1 [128][736] bf16 = value_fc1.weight with its input columns permuted to (h, w, c) and 16 zero
- * columns appended; b1, w2 float32[128]; b2 float32[1]; values bf16[n_rows].  The hidden layer stays in fp32. */
+ * columns appended; b1, w2 float32[128]; b2 float32[1]; values bf16[n_rows].  The hidden layer stays in fp32.
+ * n_rows_dev (optional, device int32): only rows below it are computed. */
 int  xq_value_head_bf16(void *hip_stream, const void *hv_dev, const void *w1_dev, const void *b1_dev, const void *w2_dev,
-                        const void *b2_dev, void *values_dev, int n_rows);
+                        const void *b2_dev, void *values_dev, int n_rows, const void *n_rows_dev);
 
 /* ------------------------------------------------------------------------------------------
  * Replay buffer: device-resident mirror of trainer.py's ReplayBuffer

@@ -82,10 +82,60 @@ def main():
         pipe.launch()
     last = pipe.drain()
     assert torch.equal(last, want[4]) and torch.equal(pipe.out[1], want[3])
+    check_broadcast_weights(rank, world)
     dist.barrier()
     if rank == 0:
         print("DIST_OK world=%d" % world)
     dist.destroy_process_group()
+
+
+def check_broadcast_weights(rank, world):
+    """SURVEY.md 8(e) "identical weights on every rank": every rank starts from DIFFERENT weights (and BatchNorm
+    statistics) and must end bit-equal to rank 0, whose own tensors must not change; the shard a rank then plays is
+    the single-rank run's (seeds base + g, checked above); ranks that disagree on the architecture all raise."""
+    import hashlib
+    from chinesechessai_amd.neural_network import ChessNet
+    torch.manual_seed(100 + rank)
+    net = ChessNet(num_blocks=1).eval()
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.normal_(0, 0.1)
+            m.running_var.uniform_(0.5, 1.5)
+            m.num_batches_tracked.fill_(7 + rank)
+
+    def digest(sd):
+        h = hashlib.sha256()
+        for k, t in sd.items():
+            h.update(k.encode())
+            h.update(t.detach().cpu().contiguous().numpy().tobytes())
+        return h.digest()
+
+    before = digest(net.state_dict())
+    nbytes = xd.broadcast_weights(net, src=0)
+    after = digest(net.state_dict())
+    assert nbytes == sum(t.numel() * (4 if t.is_floating_point() else 8) for t in net.state_dict().values())
+    mine = torch.tensor(list(after), dtype=torch.uint8)
+    every = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(every, mine)
+    assert all(torch.equal(e, every[0]) for e in every), "ranks differ after broadcast_weights"
+    if rank == 0:
+        assert after == before                         # the source's tensors are untouched
+    else:
+        assert after != before                         # (this rank really started from other weights)
+    assert int(net.bn1.num_batches_tracked) == 7       # integer buffers travel too
+    # a state_dict works as well as a module, and from another source rank
+    sd = {k: v.clone() + (rank if v.is_floating_point() else 0) for k, v in net.state_dict().items()}
+    xd.broadcast_weights(sd, src=world - 1)
+    want = net.state_dict()["conv1.weight"] + (world - 1)
+    assert torch.equal(sd["conv1.weight"], want)
+    # architecture mismatch: every rank raises, nobody hangs in the payload broadcast
+    other = ChessNet(num_blocks=1 if rank == 0 else 2)
+    try:
+        xd.broadcast_weights(other, src=0)
+        raised = False
+    except ValueError:
+        raised = True
+    assert raised
 
 
 if __name__ == "__main__":

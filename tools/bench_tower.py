@@ -44,7 +44,7 @@ NAMES[9] = "k_tower16b, 4 boards per 512-thread workgroup sharing one weight str
 NAMES[10] = "k_tower16s, 4 boards per workgroup in two groups two stage steps apart (experiment)"
 for variant in ((1, 2, 10, 9, 2, 10, 9, 2, 10) if os.environ.get("XQ_BT_SHORT") is None else (2, 10, 2, 10)):
     L.xq_tower_set_variant(variant)
-    ms = timeit(lambda: L.xq_tower_nhwc_bf16(*args))
+    ms = timeit(lambda: L.xq_tower_nhwc_bf16(*args, None, None))
     print("%s G=%d blocks=%d: %.3f ms  %.1f TFLOP/s" % (NAMES[variant], G, blocks, ms, fl / ms / 1e9))
 variant = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 L.xq_tower_set_variant(variant)

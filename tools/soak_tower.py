@@ -33,7 +33,7 @@ while time.time() - t0 < budget:
         V = torch.empty(G, 720, device="cuda", dtype=torch.bfloat16)
         _lib.check(L.xq_tower_nhwc_bf16(st, planes.data_ptr(), inet.hip_w[0].data_ptr(), inet.hip_wt.data_ptr(),
                                         inet.hip_bt.data_ptr(), inet.hip_hw.data_ptr(), inet.hip_hb.data_ptr(),
-                                        P.data_ptr(), V.data_ptr(), G, blocks))
+                                        P.data_ptr(), V.data_ptr(), G, blocks, None, None))
         outs.append((P, V))
     torch.cuda.synchronize()
     if not (torch.equal(outs[0][0], outs[2][0]) and torch.equal(outs[0][1], outs[2][1])):

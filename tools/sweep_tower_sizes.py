@@ -31,10 +31,10 @@ for G in (64, 256, 512, 1024, 1536, 2048, 3072, 4096, 8192, 16384):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             n = max(20, 20 * 4096 // G)
             for _ in range(3):
-                L.xq_tower_nhwc_bf16(*args)
+                L.xq_tower_nhwc_bf16(*args, None, None)
             e0.record()
             for _ in range(n):
-                L.xq_tower_nhwc_bf16(*args)
+                L.xq_tower_nhwc_bf16(*args, None, None)
             e1.record()
             torch.cuda.synchronize()
             b2b = e0.elapsed_time(e1) / n
@@ -42,7 +42,7 @@ for G in (64, 256, 512, 1024, 1536, 2048, 3072, 4096, 8192, 16384):
             for _ in range(10):
                 time.sleep(0.002)
                 e0.record()
-                L.xq_tower_nhwc_bf16(*args)
+                L.xq_tower_nhwc_bf16(*args, None, None)
                 e1.record()
                 torch.cuda.synchronize()
                 single.append(e0.elapsed_time(e1))

@@ -31,6 +31,6 @@ if use_stamp:
         fn(*args, stamps.data_ptr())
 else:
     for _ in range(n):
-        L.xq_tower_nhwc_bf16(*args)
+        L.xq_tower_nhwc_bf16(*args, None, None)
 torch.cuda.synchronize()
 print("done", G, blocks, variant, n)
