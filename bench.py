@@ -26,7 +26,7 @@ network rows); `value_no_carry` (every root evaluated afresh, as the reference d
 `value_full_policy_head` (all 8,100 policy columns) are measured beside it on a few extra steps.
 
 Prints ONE JSON line (rank 0).  `roofline` = the dominant kernel of the step, the hand-written
-single-launch trunk k_tower16b<PAIR> (csrc/xq_tower.hip; MFMA-bound, ~90 % of GPU time), over its full-size
+single-launch trunk k_tower16b (csrc/xq_tower.hip; MFMA-bound, ~90 % of GPU time), over its full-size
 launches (rows = games; the carried-over rounds launch it with zero rows and are listed apart); `roofline_net` =
 the whole network forward over all launches and the rows they really evaluated; `roofline_tree` = the tree/rules
 kernel k_search_round (HBM-bound integer work); all measured live with events on the stream the kernels run on.
@@ -203,7 +203,7 @@ def main():
     ap.add_argument("--tree-reuse", action="store_true", help="extension: keep the played move's subtree (no reference oracle)")
     ap.add_argument("--virtual-loss", action="store_true", help="extension: up to 8 distinct leaves per game and round (8x the network rows)")
     ap.add_argument("--fused-tower", type=int, default=1, help="1 = whole trunk in one launch (k_tower), 0 = one launch per convolution")
-    ap.add_argument("--tower-variant", type=int, default=-1, help="diagnostic: trunk kernel build (36 = default, 8 = reads clustered, 2 = 8-byte epilogue stores, 24 / 10 = k_tower16s, 1 = round 1; -1 = library default)")
+    ap.add_argument("--tower-variant", type=int, default=-1, help="diagnostic: trunk kernel build (-1 = library default: 39 from 2,048 boards up, 36 below; 36 / 39 = k_tower16b with 2 / 4 boards per workgroup; 0 = 32x32x16)")
     ap.add_argument("--conv-variant", type=int, default=0, help="diagnostic: 1 = 2 boards/WG, 2 = 4 boards/WG (0 = library default)")
     args = ap.parse_args()
     if args.gpus < 1:
@@ -512,14 +512,18 @@ def run_rank(args):
         if fused:       # k_tower: conv1 + 2*blocks convs + both heads per launch
             per_board = 2.0 * 90 * (16 * 9 * 128 + 2 * args.blocks * 128 * 9 * 128 + 128 * 40)
             rows_tw = rows_fw if len(tw_t) == len(rows_fw) else np.full(len(tw_t), rows, np.int64)
-            full = rows_tw == rows                              # full-size launches: every slot has a row
+            # full-size launches: (nearly) every slot has a row - a round in which a few games ended on a terminal leaf or
+            # are already over still is one; their flops are counted by the rows they really ran
+            full = rows_tw >= 0.98 * rows
             n_conv = int(full.sum())
             conv_ms = float(tw_t[full].sum())
-            conv_fl = per_board * rows
-            launches = {"full": n_conv, "empty": int((rows_tw == 0).sum()), "partial": int(((rows_tw > 0) & ~full).sum()),
+            conv_fl = per_board * float(rows_tw[full].mean()) if n_conv else per_board * rows
+            launches = {"full_size": n_conv, "rows_avg_full_size": float(rows_tw[full].mean()) if n_conv else None,
+                        "empty": int((rows_tw == 0).sum()), "partial": int(((rows_tw > 0) & ~full).sum()),
                         "empty_ms_avg": float(tw_t[rows_tw == 0].mean()) if (rows_tw == 0).any() else None,
-                        "all_ms": float(tw_t.sum())}
-            kname, kdesc = "k_tower", "k_tower16b<PAIR>, hand-written single-launch trunk on v_mfma_f32_16x16x32_bf16: conv3x3(16->128) + %d fused residual convs + 1x1 heads, activations resident in LDS" % (2 * args.blocks)
+                        "all_launches": int(len(tw_t)), "all_ms": float(tw_t.sum())}
+            kname, kdesc = "k_tower", "k_tower16b<NB = %d>, hand-written single-launch trunk on v_mfma_f32_16x16x32_bf16: conv3x3(16->128) + %d fused residual convs + 1x1 heads, activations resident in LDS, %d boards per workgroup share one weight stream" % (
+                4 if rows >= 2048 else 2, 2 * args.blocks, 4 if rows >= 2048 else 2)
         else:
             n_conv = 2 * args.blocks * len(tw_t)
             conv_ms = float(tw_t.sum())
@@ -538,8 +542,8 @@ def run_rank(args):
         if carry_on:
             extras.append("; root evaluation carry-over ON (result-identical, tested at this size: the new root's priors are the "
                           "ones the played child received during the previous ply's search, so round 0 of every ply after the "
-                          "first has no network rows: %d full-size forwards in this run instead of %d; value_no_carry is the "
-                          "figure with every root evaluated afresh)" % (int((rows_fw == rows).sum()), n_fw))
+                          "first has no network rows: %d forwards with rows in this run instead of %d; value_no_carry is the "
+                          "figure with every root evaluated afresh)" % (int((rows_fw > 0).sum()), n_fw))
         if eng.row_compaction:
             extras.append("; evaluator row compaction (only slots with a pending leaf are network rows)")
         if args.tree_reuse:
@@ -564,8 +568,9 @@ def run_rank(args):
             "roofline": {"bound": "mfma", "achieved": conv_tflops, "peak": MFMA_PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": conv_tflops / MFMA_PEAK_BF16_TFLOPS,
                          "traffic": tr_tower[0], "traffic_source": tr_tower[1],
-                         "kernel": "%s (%s; %d full-size launches of %d boards, %.4f ms avg; %.0f%% of the step)" % (
-                             kname, kdesc, n_conv, rows, conv_ms / max(n_conv, 1), 100.0 * conv_ms / (dt * 1e3)),
+                         "kernel": "%s (%s; %d full-size launches of %d boards on average, %.4f ms avg; %.0f%% of the step)" % (
+                             kname, kdesc, n_conv, int(round(conv_fl / (per_board if fused else conv_fl / rows))), conv_ms / max(n_conv, 1),
+                             100.0 * conv_ms / (dt * 1e3)),
                          "flops_per_launch": conv_fl, "launches": launches},
             "roofline_net": {"bound": "mfma", "achieved": net_tflops, "peak": MFMA_PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                              "frac": net_tflops / MFMA_PEAK_BF16_TFLOPS, "traffic": None,

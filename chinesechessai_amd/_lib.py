@@ -12,7 +12,7 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libxq_hip.so")
 SOURCES = [os.path.join(CSRC, "xq_engine.hip"), os.path.join(CSRC, "xq_conv.hip"), os.path.join(CSRC, "xq_replay.hip"),
            os.path.join(CSRC, "xq_tower.hip"), os.path.join(CSRC, "xq_policy.hip")]
-HEADERS = [os.path.join(CSRC, "xq_device.hpp"), os.path.join(CSRC, "xq_mfma.hpp"),
+HEADERS = [os.path.join(CSRC, "xq_device.hpp"), os.path.join(CSRC, "xq_mfma.hpp"), os.path.join(CSRC, "xq_tower_probes.hpp"),
            os.path.join(_HERE, "..", "include", "xq_selfplay.h")]
 
 MAX_MOVES = 128
@@ -48,8 +48,8 @@ def hipcc_path():
 def build(force=False, verbose=False):
     """Cross-compile the HIP library for gfx950 in-tree (works without a GPU)."""
     deps = SOURCES + HEADERS
-    # XQ_TOWER_PROBES=1 in the environment also compiles the trunk kernel's ablation / option builds (timing probes
-    # behind xq_tower_debug_stamps: tools/bench_tower.py, tools/probe_tiles.py); the default library leaves them out
+    # XQ_TOWER_PROBES=1 in the environment also compiles csrc/xq_tower_probes.hpp: the trunk kernel's experiments and timing
+    # probes (tools/bench_tower.py, tools/probe_tiles.py, tools/probe_loop.py); the default library leaves them out
     probes = os.environ.get("XQ_TOWER_PROBES", "0") == "1"
     flagfile = os.path.join(CSRC, "build", "flags.txt")
     built_with = open(flagfile).read().strip() if os.path.exists(flagfile) else ""

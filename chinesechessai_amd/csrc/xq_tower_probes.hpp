@@ -1,0 +1,732 @@
+// xq_tower_probes.hpp - experiments and timing probes of the trunk kernel, compiled only with -DXQ_TOWER_PROBES=1
+// (XQ_TOWER_PROBES=1 in the environment of _lib.build; tools/probe_tiles.py, tools/probe_loop.py, tools/bench_tower.py).
+// The product library carries none of this.  Included by xq_tower.hip inside its translation unit (it uses TowerArgs,
+// the LDS constants and k_tower16b's conventions).
+//   k_tower1w        round 3: ONE wave per SIMD, 128 x 96 wave tile, accumulators on fixed AGPRs - bit-identical to the
+//                    product kernel, holds 2.3 GHz, loses on cycles
+//   k_loop_probe     the main loop alone (no barriers, no epilogues) for the 64 x 96 / 128 x 96 wave tiles
+//   k_mfma_probe*    bare MFMA loops: what the matrix pipes sustain under the board's power management
+#pragma once
+
+namespace {
+// ------------------------------------------------------------------------------------------
+// k_tower1w — ONE wave per SIMD: a 256-thread workgroup carries 4 boards, each wave owns a whole board and all 128
+// output channels of it (wave tile 128 channels x 96 pixels = 8 x 6 MFMA tiles, 192 accumulator registers in
+// AGPRs), one workgroup per CU, one weight stream per 4 boards through a ring of 4 stages.
+// Why (round 3): the two-waves-per-SIMD builds are bounded by the chip's power management, not by cycles; what is
+// left to save is data movement per MFMA.  This tile reads 14 fragments per 48 MFMAs instead of 10 per 24 (-30 %
+// LDS bytes), halves the L2 -> LDS weight stream per board, and has no second wave to arbitrate with (the shared
+// stage barrier of k_tower16s lost what the halved stream gained because the older wave of a SIMD always won).
+// Nothing crosses waves but the weight ring: a board's layer hand-over is wave-local (LDS serves one wave's
+// operations in order), so the only workgroup barriers are the stage barriers, with the DMA two stages ahead
+// (counted vmcnt(4)).  The price: no partner wave covers an epilogue.
+// Same LDS images, swizzles, channel deal (PAIR), weight-source permutation and accumulation order as
+// k_tower16b<PAIR>: the results are bit-identical to it.
+// ------------------------------------------------------------------------------------------
+// Accumulators named literally (a[4 t .. 4 t + 3] for tile t): hipcc keeps 192 accumulator registers in AGPRs only
+// with two to three v_accvgpr copies per MFMA in the loop (untied AGPR-form MFMAs rotated through staging tuples),
+// so the one-wave-per-SIMD builds issue their MFMAs as asm statements on fixed AGPRs.  The compiler never sees these
+// registers: XQ_AGPR_ALL (one statement, at kernel entry) makes it account for them in the kernel descriptor, and
+// every build is checked (ISA) for AGPR uses of its own.
+#define XQ_A8(b) "a" #b "0", "a" #b "1", "a" #b "2", "a" #b "3", "a" #b "4", "a" #b "5", "a" #b "6", "a" #b "7", "a" #b "8", "a" #b "9"
+#define XQ_AGPR_ALL() asm volatile("" ::: "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", XQ_A8(1), XQ_A8(2), XQ_A8(3), XQ_A8(4), \
+    XQ_A8(5), XQ_A8(6), XQ_A8(7), XQ_A8(8), XQ_A8(9), XQ_A8(10), XQ_A8(11), XQ_A8(12), XQ_A8(13), XQ_A8(14), XQ_A8(15), XQ_A8(16), \
+    XQ_A8(17), XQ_A8(18), "a190", "a191")
+template <int T> __device__ __forceinline__ void amfma(const bf16x8 &a, const bf16x8 &b)
+{
+    asm volatile("v_mfma_f32_16x16x32_bf16 a[%0:%1], %2, %3, a[%0:%1]" : : "n"(4 * T), "n"(4 * T + 3), "v"(a), "v"(b));
+}
+// the same behind two wait states: for operands the compiler may still be assembling with VALU moves right in front of
+// the statement (VALU write -> MFMA source read needs wait states that hipcc does not insert for an asm MFMA: a selector
+// built by v_perm / v_mov directly in front of its first MFMA was read stale)
+template <int T> __device__ __forceinline__ void amfma_guarded(const bf16x8 &a, const bf16x8 &b)
+{
+    asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 a[%0:%1], %2, %3, a[%0:%1]" : : "n"(4 * T), "n"(4 * T + 3), "v"(a), "v"(b));
+}
+template <int T> __device__ __forceinline__ void aset(const f32x4 &v)          // a[4T .. 4T+3] = v
+{
+    asm volatile("v_accvgpr_write_b32 a[%0], %4\n\tv_accvgpr_write_b32 a[%1], %5\n\tv_accvgpr_write_b32 a[%2], %6\n\tv_accvgpr_write_b32 a[%3], %7"
+                 : : "n"(4 * T), "n"(4 * T + 1), "n"(4 * T + 2), "n"(4 * T + 3), "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
+}
+template <int T> __device__ __forceinline__ f32x4 aget()
+{
+    float x0, x1, x2, x3;
+    asm volatile("v_accvgpr_read_b32 %0, a[%4]\n\tv_accvgpr_read_b32 %1, a[%5]\n\tv_accvgpr_read_b32 %2, a[%6]\n\tv_accvgpr_read_b32 %3, a[%7]"
+                 : "=v"(x0), "=v"(x1), "=v"(x2), "=v"(x3) : "n"(4 * T), "n"(4 * T + 1), "n"(4 * T + 2), "n"(4 * T + 3));
+    return f32x4{ x0, x1, x2, x3 };
+}
+// compile-time loops over tiles (the tile index must be a constant expression for the asm templates)
+template <int... Ts> __device__ __forceinline__ void aset_all(std::integer_sequence<int, Ts...>, const f32x4 &v) { (aset<Ts>(v), ...); }
+template <int N0, int... Ms> __device__ __forceinline__ void amfma_col(std::integer_sequence<int, Ms...>, const bf16x8 *fa, const bf16x8 &fb)
+{
+    (amfma<Ms * 6 + N0>(fa[Ms], fb), ...);
+}
+
+
+#ifndef XQ_1W_DEBUG_WAIT
+#define XQ_1W_DEBUG_WAIT 0x0F74      // vmcnt(4); -DXQ_1W_DEBUG_WAIT=0x0070 drains everything at every stage barrier
+#endif
+constexpr int RING1W = 4;
+constexpr int LDS_BYTES1W = RING1W * WBUF_BYTES + 4 * ACT_BYTES + 256 + 2 * 512;
+
+template <int N0, int... Ms> __device__ __forceinline__ void aset_col(std::integer_sequence<int, Ms...>, const f32x4 *b)
+{
+    (aset<Ms * 6 + N0>(b[Ms]), ...);
+}
+// two floats -> packed bf16 + ReLU without an asm statement (hipcc selects v_cvt_pk_bf16_f32 for the vector conversion and
+// can schedule it; the asm form of xq_mfma.hpp costs a boundary s_nop per use)
+__device__ __forceinline__ uint32_t pack_relu_bf16x2(float a, float b)
+{
+    typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+    typedef __attribute__((ext_vector_type(2))) short s16x2_t;
+    const bf16x2_t h = __builtin_convertvector((f32x2_t){ a, b }, bf16x2_t);
+    s16x2_t v = *reinterpret_cast<const s16x2_t *>(&h);
+    v = __builtin_elementwise_max(v, (s16x2_t){ 0, 0 });
+    return *reinterpret_cast<const uint32_t *>(&v);
+}
+// a[4T .. 4T+3] = 16 bytes of LDS at addr + OFF: the accumulator's start value (a layer's bias) without a VALU instruction.
+// An asm load is outside hipcc's s_waitcnt bookkeeping: the caller waits with await_lds() before the registers are used
+// (the compiler's own counted waits stay correct: extra operations in the in-order LDS queue only make them conservative).
+template <int T, int OFF> __device__ __forceinline__ void aload(int addr)
+{
+    asm volatile("ds_read_b128 a[%0:%1], %2 offset:%3" : : "n"(4 * T), "n"(4 * T + 3), "v"(addr), "n"(OFF) : "memory");
+}
+__device__ __forceinline__ void await_lds() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// epilogue of pixel tile N of channel pair J: the lane's 8 consecutive channels (tiles 2J, 2J + 1) -> bf16 -> ReLU -> 16 bytes
+template <int J, int N> __device__ __forceinline__ uint4 epi_get()
+{
+    const f32x4 v0 = aget<(2 * J) * 6 + N>(), v1 = aget<(2 * J + 1) * 6 + N>();
+    return make_uint4(pack_relu_bf16x2(v0[0], v0[1]), pack_relu_bf16x2(v0[2], v0[3]),
+                      pack_relu_bf16x2(v1[0], v1[1]), pack_relu_bf16x2(v1[2], v1[3]));
+}
+// first half of a pair's epilogue: [x fragments in,] results out, next layer's bias into the accumulators
+template <int J, bool READ_X, int... Ns>
+__device__ __forceinline__ void epi_pair(std::integer_sequence<int, Ns...>, const int *sb, bool tail_ok, int lbq, bf16x8 *xf)
+{
+    if constexpr (READ_X) ((xf[Ns] = lds_ld128(sb[Ns] ^ (J << 5))), ...);          // the block input x: the chunk this lane overwrites
+    uint4 pk[6];
+    ((pk[Ns] = epi_get<J, Ns>()), ...);
+    ((Ns < 5 || tail_ok ? lds_st128(sb[Ns] ^ (J << 5), pk[Ns]) : (void)0), ...);
+    ((aload<(2 * J) * 6 + Ns, J * 128>(lbq), aload<(2 * J + 1) * 6 + Ns, J * 128 + 16>(lbq)), ...);
+}
+// second half (first convolution of a block): + x through the matrix pipe, S . X with a 0/1 selector S
+template <int J, int... Ns>
+__device__ __forceinline__ void epi_skip(std::integer_sequence<int, Ns...>, const bf16x8 *sel, const bf16x8 *xf)
+{
+    ((amfma_guarded<(2 * J) * 6 + Ns>(sel[0], xf[Ns]), amfma_guarded<(2 * J + 1) * 6 + Ns>(sel[1], xf[Ns])), ...);
+}
+
+template <bool STAMP>
+__global__ __launch_bounds__(256, 1) void k_tower1w(TowerArgs A)
+{
+    constexpr int NB = 4, PPW = 4;                                       // boards = waves, weight pieces per wave and stage
+    constexpr int ACT0 = RING1W * WBUF_BYTES, ZROW = ACT0 + NB * ACT_BYTES, BIAS = ZROW + 256;   // bias: [2][128] f32
+    using seq8 = std::make_integer_sequence<int, 8>;
+    using seq6 = std::make_integer_sequence<int, 6>;
+
+    auto stamp = [&](int slot) {
+        if constexpr (STAMP) {
+            const unsigned long long t = __builtin_amdgcn_s_memtime();
+            if (threadIdx.x == 0) A.stamps[(size_t)blockIdx.x * 64 + slot] = t;
+            if (slot == 0 || slot == 61) {
+                const unsigned long long rt = __builtin_amdgcn_s_memrealtime();
+                if (threadIdx.x == 0) A.stamps[(size_t)blockIdx.x * 64 + (slot == 0 ? 62 : 63)] = rt;
+            }
+        }
+    };
+    stamp(0);
+    XQ_AGPR_ALL();
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    auto chan_row = [&](int mt, int i) { return (mt >> 1) * 32 + (i >> 2) * 8 + (mt & 1) * 4 + (i & 3); };
+    int nrows = A.G;
+    if (A.n_rows) { const int n = *A.n_rows; nrows = n < A.G ? n : A.G; }
+    if ((int)blockIdx.x * NB >= nrows) return;     // compaction: no row for this workgroup (uniform, before any barrier / DMA)
+    const int board = blockIdx.x * NB + wave;
+    const bool board_ok = board < nrows;
+    const int act_off = ACT0 + wave * ACT_BYTES;
+    const int r16 = lane & 15, q = lane >> 4;
+
+    // ---------------------------------------------------------------- input conv (16 -> 128)
+    const int pl_off = act_off + ACT_BYTES - PIX * 32;
+    if (tid < 16) lds_st128(ZROW + tid * 16, make_uint4(0, 0, 0, 0));
+    const int nlayers = 2 * A.nblocks, nstages = nlayers * 18;
+    if (wave == 1 && lane < 32 && nstages > 0) dma16_abs(A.bias + 128 + lane * 4, BIAS + 512);   // bias[1] -> slot 1
+#pragma unroll
+    for (int j = 0; j < 9; j++) {
+        const int piece = j * 4 + wave;
+        dma16_abs(reinterpret_cast<const uint8_t *>(A.w1) + piece * 1024 + lane * 16, piece * 1024);
+    }
+    if (board_ok) {
+        const int srow = A.row_src ? A.row_src[board] : board;
+        const uint8_t *src = reinterpret_cast<const uint8_t *>(A.planes) + (size_t)srow * PIX * 32;
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const int idx = j * 64 + lane;
+            if (idx < PIX * 2) dma16_abs(src + idx * 16, pl_off + j * 1024);
+        }
+    }
+    {
+        f32x4 b8[8];
+#pragma unroll
+        for (int mt = 0; mt < 8; mt++) b8[mt] = *reinterpret_cast<const f32x4 *>(A.bias + chan_row(mt, 4 * q));
+        aset_col<0>(seq8{}, b8); aset_col<1>(seq8{}, b8); aset_col<2>(seq8{}, b8);
+        aset_col<3>(seq8{}, b8); aset_col<4>(seq8{}, b8); aset_col<5>(seq8{}, b8);
+    }
+    barrier_dma();
+    {
+        uint32_t vm[2] = { 0, 0 };        // tap validity of the 6 pixels of this lane, 9 bits each
+#pragma unroll
+        for (int nt = 0; nt < 6; nt++) {
+            const int o = nt * 16 + r16;
+            uint32_t m = 0;
+            if (o < PIX) {
+                const int yy = o / 9, xx = o % 9;
+#pragma unroll
+                for (int t = 0; t < 9; t++) {
+                    const int dy = t / 3 - 1, dx = t % 3 - 1;
+                    if (yy + dy >= 0 && yy + dy < 10 && xx + dx >= 0 && xx + dx < 9) m |= 1u << t;
+                }
+            }
+            vm[nt / 3] |= m << ((nt % 3) * 9);
+        }
+#pragma unroll
+        for (int pair = 0; pair < 5; pair++) {                       // K-step = taps (2 pair, 2 pair + 1) x 16 planes
+            const int tap = 2 * pair + (q >> 1);
+            const bool tap_real = tap < 9;
+            const int tp = tap_real ? tap : 8;
+            const int off = (tp / 3 - 1) * 9 + (tp % 3 - 1);
+            bf16x8 bf[6], af[8];
+#pragma unroll
+            for (int nt = 0; nt < 6; nt++) {
+                const bool ok = tap_real && ((vm[nt / 3] >> ((nt % 3) * 9 + tp)) & 1u);
+                const int sp = nt * 16 + r16 + off;
+                bf[nt] = lds_ld128((ok ? pl_off + sp * 32 : ZROW + (sp & 7) * 32) + (q & 1) * 16);
+            }
+#pragma unroll
+            for (int mt = 0; mt < 8; mt++)
+                af[mt] = lds_ld128((tp * COUT + chan_row(mt, r16)) * 32 + (q & 1) * 16);
+            __builtin_amdgcn_sched_barrier(0);
+            amfma_col<0>(seq8{}, af, bf[0]); amfma_col<1>(seq8{}, af, bf[1]); amfma_col<2>(seq8{}, af, bf[2]);
+            amfma_col<3>(seq8{}, af, bf[3]); amfma_col<4>(seq8{}, af, bf[4]); amfma_col<5>(seq8{}, af, bf[5]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    barrier_dma();                                                 // every wave is done with the tap slices (ring area)
+    stamp(1);
+
+    // weight stream: stage g = (layer, tap, K-slice) -> ring slot g & 3, 16 pieces of 1 KB, 4 per wave
+    const rsrc_t wrsrc = make_rsrc(A.wt, nlayers * 9 * COUT * COUT * 2);
+    const int wch = (lane & 7) ^ (lane >> 4);
+    const int wsrc_even = ((lane >> 5) * 8 + ((lane >> 3) & 3)) * 256 + (wch << 4), wsrc_odd = wsrc_even ^ 64;
+    auto piece_off = [&](int P) { return ((P >> 3) * 64 + ((P >> 2) & 1) * 32 + (P & 1) * 16 + ((P >> 1) & 1) * 4) * 256; };
+    auto stage_piece = [&](int g, int j) {                            // piece j (< PPW) of this wave, stage g -> slot g & 3
+        const int gg = g < nstages ? g : nstages - 1;                 // (past the end: a harmless refetch, no branch)
+        const int soff = (gg >> 1) * (COUT * COUT * 2) + (gg & 1) * 128 + piece_off(wave * PPW + j);
+        dma16_buf_abs(wrsrc, (j & 1) ? wsrc_odd : wsrc_even, soff, (g & 3) * WBUF_BYTES + (wave * PPW + j) * 1024);
+    };
+    const int abase = r16 * 128 + ((q ^ ((r16 >> 1) & 7)) << 4);
+    int bsel[2] = { abase, abase + 2 * WBUF_BYTES };                   // ring slot of stage p of a layer = (p & 3) ^ (2 * (layer & 1))
+    auto load_a1 = [&](bf16x8 &af, int mt, int p, int kk) {
+        af = lds_ld128((bsel[(p >> 1) & 1] ^ (kk << 6)) + (p & 1) * WBUF_BYTES + mt * 2048);
+    };
+
+    bool xl[6], xr[6];
+#pragma unroll
+    for (int nt = 0; nt < 6; nt++) {
+        const int p = nt * 16 + r16, xx = p % 9;
+        xl[nt] = xx != 0 && p < PIX;
+        xr[nt] = xx != 8 && p < PIX;
+    }
+    const bool real5 = r16 < PIX - 80, yu0 = r16 >= 9, yd5 = r16 == 0;
+    const int Rrow = act_off + r16 * 256, r5 = r16 << 4, q4 = (((q & 1) << 3) | (q >> 1)) << 4;
+    auto tap_addrs = [&](int (&as)[6], int tap) {
+        const int dy = tap / 3 - 1, dx = tap % 3 - 1, off = dy * 9 + dx;
+        int rrow = Rrow, r5o = r5;
+        asm volatile("" : "+v"(rrow), "+v"(r5o));
+        const int slot = ((r5o + off * 16) & 0x70) ^ q4;
+        const int aok = rrow + off * 256 + slot;
+#pragma unroll
+        for (int nt = 0; nt < 6; nt++) {
+            const bool sel = dx != 0 || (nt == 0 && dy < 0) || nt == 5;
+            if (!sel) { as[nt] = aok; continue; }
+            bool ok = dx < 0 ? xl[nt] : dx > 0 ? xr[nt] : real5;
+            if (dx == 0 && nt == 0) ok = yu0;
+            else if (nt == 0 && dy < 0) ok = ok && yu0;
+            if (nt == 5 && dy > 0) ok = ok && yd5;
+            as[nt] = ok ? aok : slot + (ZROW - nt * 4096);
+        }
+    };
+    auto load_b1 = [&](bf16x8 &bf, int a, int nt, int ks) { bf = lds_ld128((a ^ (ks << 5)) + nt * 4096); };
+
+    // epilogue of one layer (wave-local): acc -> bf16 -> ReLU -> LDS rows in place; the next layer's accumulators start
+    // at its bias (+ the block input x for the second convolution of a block, read back from the rows being overwritten)
+    auto epilogue = [&](auto read_x, int lb_next) {
+        constexpr bool RX = decltype(read_x)::value;
+        int ln;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
+        const int r = ln & 15, qq = ln >> 4;
+        int sb[6];                                                    // this lane's chunk of K-step 0 (pair j: ^ (j << 5)) of pixel nt * 16 + r
+#pragma unroll
+        for (int nt = 0; nt < 6; nt++) {
+            const int p = nt * 16 + r < PIX ? nt * 16 + r : 0;
+            sb[nt] = act_off + p * 256 + (((((qq & 1) << 3) | (qq >> 1)) ^ (p & 7)) << 4);
+        }
+        const int lbq = lb_next + qq * 8 * 4;                          // bias of channel j * 32 + qq * 8 + t * 4 ..
+        bf16x8 sel[2];
+        if constexpr (RX) {
+#pragma unroll
+            for (int o = 0; o < 2; o++)
+#pragma unroll
+                for (int j = 0; j < 8; j++)
+                    sel[o][j] = (qq == (r >> 2) && j == o * 4 + (r & 3)) ? (__bf16)1.0f : (__bf16)0.0f;
+        }
+        const bool tail_ok = r < PIX - 80;
+        bf16x8 xf[4][6];
+        asm volatile("s_nop 15\n\ts_nop 15");                          // the layer's last MFMAs -> v_accvgpr_read (no interlock for asm)
+        epi_pair<0, RX>(seq6{}, sb, tail_ok, lbq, xf[0]);
+        epi_pair<1, RX>(seq6{}, sb, tail_ok, lbq, xf[1]);
+        epi_pair<2, RX>(seq6{}, sb, tail_ok, lbq, xf[2]);
+        epi_pair<3, RX>(seq6{}, sb, tail_ok, lbq, xf[3]);
+        await_lds();                                                   // the bias values are in the accumulators
+        if constexpr (RX) {
+            epi_skip<0>(seq6{}, sel, xf[0]); epi_skip<1>(seq6{}, sel, xf[1]);
+            epi_skip<2>(seq6{}, sel, xf[2]); epi_skip<3>(seq6{}, sel, xf[3]);
+        }
+    };
+    using yes = std::integral_constant<bool, true>;
+    using no = std::integral_constant<bool, false>;
+
+    if (nstages > 0) {
+#pragma unroll
+        for (int j = 0; j < PPW; j++) { stage_piece(0, j); stage_piece(1, j); stage_piece(2, j); }
+    }
+    epilogue(no{}, BIAS + 512);                                     // conv1 output; tower layer 0 starts at bias[1]
+    barrier_dma();                                                 // stages 0..2 and bias[1] have landed, for every wave
+    stamp(2);
+
+    // ---------------------------------------------------------------- residual tower
+    bf16x8 fa[2][8], fb[2][6];                                       // fragments, double-buffered by K-step parity
+    for (int layer = 0; layer < nlayers; layer++) {
+        const int base = layer * 18, par = layer & 1;
+        bsel[0] = abase + par * 2 * WBUF_BYTES;
+        bsel[1] = abase + (par ^ 1) * 2 * WBUF_BYTES;
+        if (wave == 1 && lane < 32 && layer + 1 < nlayers)          // bias of tower layer L + 1 (row L + 2) -> slot L & 1
+            dma16_abs(A.bias + (size_t)(layer + 2) * 128 + lane * 4, BIAS + (layer & 1) * 512);
+#pragma unroll
+        for (int mt = 0; mt < 8; mt++) load_a1(fa[0][mt], mt, 0, 0);
+        int as[6];
+        tap_addrs(as, 0);
+#pragma unroll
+        for (int nt = 0; nt < 6; nt++) load_b1(fb[0][nt], as[nt], nt, 0);
+#pragma unroll
+        for (int tap = 0; tap < 9; tap++) {
+            int asn[6];
+#pragma unroll
+            for (int ks = 0; ks < 4; ks++) {                        // 4 K-steps of 32 channels = 2 weight stages
+                const int sl = ks >> 1, kk = ks & 1, cur = ks & 1;
+                const int p = tap * 2 + sl;                           // stage of the layer
+                const bool last = tap == 8 && ks == 3;                // last K-step of the layer: no activation prefetch
+                if (ks == 3 && !last) tap_addrs(asn, tap + 1);
+#pragma unroll
+                for (int n = 0; n < 6; n++) {                        // pixel tile n: 8 MFMAs
+                    // the next K-step's fragments: the activation fragment of this tile, one or two weight fragments
+                    if (!last) {
+                        if (ks < 3) load_b1(fb[cur ^ 1][n], as[n], n, ks + 1);
+                        else load_b1(fb[cur ^ 1][n], asn[n], n, 0);
+                    }
+                    if (kk == 0) {                                    // from this stage: tiles 0, 1 fetch two each, 2..5 one each
+                        if (n < 2) { load_a1(fa[cur ^ 1][2 * n], 2 * n, p, 1); load_a1(fa[cur ^ 1][2 * n + 1], 2 * n + 1, p, 1); }
+                        else load_a1(fa[cur ^ 1][n + 2], n + 2, p, 1);
+                    } else if (n >= 1) {                              // from the stage the barrier (behind tile 0) published
+                        if (n < 4) { load_a1(fa[cur ^ 1][2 * n - 2], 2 * n - 2, p + 1, 0); load_a1(fa[cur ^ 1][2 * n - 1], 2 * n - 1, p + 1, 0); }
+                        else load_a1(fa[cur ^ 1][n + 2], n + 2, p + 1, 0);
+                        if (n - 1 < PPW) stage_piece(base + p + 3, n - 1);      // the slot stage p - 1 has left, three stages ahead
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    switch (n) {
+                    case 0: amfma_col<0>(seq8{}, fa[cur], fb[cur][0]); break;
+                    case 1: amfma_col<1>(seq8{}, fa[cur], fb[cur][1]); break;
+                    case 2: amfma_col<2>(seq8{}, fa[cur], fb[cur][2]); break;
+                    case 3: amfma_col<3>(seq8{}, fa[cur], fb[cur][3]); break;
+                    case 4: amfma_col<4>(seq8{}, fa[cur], fb[cur][4]); break;
+                    default: amfma_col<5>(seq8{}, fa[cur], fb[cur][5]); break;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (kk == 1 && n == 0) {
+                        // stage barrier B_p: the pieces of stage p + 1 (issued two barriers ago) have landed - each wave
+                        // waits for its own, leaving the 4 of stage p + 2 in flight - and every wave has finished with
+                        // stage p - 1, whose slot the pieces issued behind this barrier refill
+                        __builtin_amdgcn_s_waitcnt(XQ_1W_DEBUG_WAIT);           // vmcnt(4)
+                        __builtin_amdgcn_s_barrier();
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+            if (tap < 8) {
+#pragma unroll
+                for (int nt = 0; nt < 6; nt++) as[nt] = asn[nt];
+            }
+        }
+        if (layer < 28) stamp(3 + 2 * layer);
+        if (layer & 1) epilogue(no{}, BIAS + (layer & 1) * 512);
+        else epilogue(yes{}, BIAS + (layer & 1) * 512);
+        if (layer < 28) stamp(4 + 2 * layer);
+    }
+
+    // ---------------------------------------------------------------- heads (1x1, 128 -> 32 + 8): policy rows 0..31, value rows 32..47
+    __builtin_amdgcn_s_waitcnt(0x0070);                              // vmcnt(0) lgkmcnt(0): no tower DMA in flight, own reads done
+    __syncthreads();                                                 // ... for every wave: the ring area is free
+    {
+        const uint8_t *src = reinterpret_cast<const uint8_t *>(A.wh);     // [64][256 B], chunk ^ ((row & 7) << 1)
+#pragma unroll
+        for (int j = 0; j < PPW; j++) {
+            const int q0 = (wave * PPW + j) * 64, idx = q0 + lane, row = idx >> 4, cp = idx & 15;
+            dma16_abs(src + row * 256 + ((cp ^ ((row & 7) << 1)) * 16), q0 * 16);
+        }
+    }
+    f32x4 hacc[3][6];
+#pragma unroll
+    for (int m = 0; m < 3; m++)
+#pragma unroll
+        for (int nt = 0; nt < 6; nt++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) hacc[m][nt][i] = 0.f;
+    barrier_dma();
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) {
+        bf16x8 hb[6], ha[3];
+#pragma unroll
+        for (int nt = 0; nt < 6; nt++) {
+            const int p = nt * 16 + r16 < PIX ? nt * 16 + r16 : 0;
+            hb[nt] = lds_ld128(act_off + p * 256 + (((((q & 1) << 3) | (ks << 1) | (q >> 1)) ^ (p & 7)) << 4));
+        }
+#pragma unroll
+        for (int m = 0; m < 3; m++) {
+            const int row = m * 16 + r16;
+            ha[m] = lds_ld128(row * 256 + (((ks * 4 + q) ^ ((row & 7) << 1)) << 4));
+        }
+#pragma unroll
+        for (int m = 0; m < 3; m++)
+#pragma unroll
+            for (int nt = 0; nt < 6; nt++)
+                hacc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ha[m], hb[nt], hacc[m][nt], 0, 0, 0);
+    }
+    stamp(60);
+    if (!board_ok) { stamp(61); return; }
+    uint8_t *Pb = reinterpret_cast<uint8_t *>(A.P) + (size_t)board * PIX * 64;
+    uint8_t *Vb = reinterpret_cast<uint8_t *>(A.V) + (size_t)board * PIX * 16;
+#pragma unroll
+    for (int m = 0; m < 3; m++) {
+        const int c0 = m * 16 + 4 * q;                               // head channel of element 0
+        const f32x4 b4 = *reinterpret_cast<const f32x4 *>(A.bh + c0);
+#pragma unroll
+        for (int nt = 0; nt < 6; nt++) {
+            const int p = nt * 16 + r16;
+            if (p < PIX && (m < 2 || q < 2)) {                       // value head: channels 32..39 only
+                const float v0 = hacc[m][nt][0] + b4[0], v1 = hacc[m][nt][1] + b4[1];
+                const float v2 = hacc[m][nt][2] + b4[2], v3 = hacc[m][nt][3] + b4[3];
+                const uint2 pk = make_uint2(relu_bf16x2(pack_bf16x2(v0, v1)), relu_bf16x2(pack_bf16x2(v2, v3)));
+                if (m < 2) *reinterpret_cast<uint2 *>(Pb + p * 64 + c0 * 2) = pk;
+                else *reinterpret_cast<uint2 *>(Vb + p * 16 + (c0 - 32) * 2) = pk;
+            }
+        }
+    }
+    stamp(61);
+}
+
+}  // namespace
+
+// diagnostic only: what the matrix pipes sustain under this board's power cap — 2 waves per SIMD
+// issuing v_mfma_f32_32x32x16_bf16 back to back (6 accumulators per wave like the conv tile).
+//   mode 0: operands fixed in registers (no other activity)
+//   mode 1: operands re-read from LDS for every K-step in the conv's 2 A + 3 B pattern (random bf16
+//           data, half of the B values zero like post-ReLU activations), no barriers, no DMA
+//   mode 2: mode 1 + the conv's weight stream (4 LDS-DMA pieces of 1 KB per 24 MFMAs from a 3.5 MB
+//           L2-resident buffer), still no barriers
+// tools/bench_tower.py prints these beside the kernel: the gap between them is what the data
+// movement costs in clock under the power cap.
+namespace {
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void k_mfma_probe(const uint32_t *seed, const uint8_t *wsrc, float *out, int iters)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    uint32_t s = seed[lane] + blockIdx.x * 2654435761u + tid * 40503u;
+    auto rnd = [&]() { s = s * 1664525u + 1013904223u; return s; };
+    if (MODE > 0) {
+        // 32 KB "weights" (dense random) + 46 KB "activations" (half zeros), bf16 in [-1, 1)
+        for (int i = tid; i < (32768 + 46080) / 4; i += 256) {
+            const uint32_t r = rnd();
+            const float a = ((int)((r >> 8) & 2047) - 1024) * (1.0f / 1024.0f), b = ((int)((r >> 20) & 2047) - 1024) * (1.0f / 1024.0f);
+            uint32_t w = pack_bf16x2(a, b);
+            if (i >= 8192) w = relu_bf16x2(w);
+            reinterpret_cast<uint32_t *>(lds)[i] = w;
+        }
+        barrier_dma();
+    }
+    bf16x8 a[2], b[3];
+    for (int i = 0; i < 8; i++) {
+        a[0][i] = (__bf16)(((int)(rnd() >> 9) % 2048 - 1024) * (1.0f / 1024.0f));
+        a[1][i] = (__bf16)(((int)(rnd() >> 9) % 2048 - 1024) * (1.0f / 1024.0f));
+        for (int n = 0; n < 3; n++) {
+            const float v = ((int)(rnd() >> 9) % 2048 - 1024) * (1.0f / 1024.0f);
+            b[n][i] = (__bf16)(v > 0.f ? v : 0.f);
+        }
+    }
+    f32x16 acc[2][3];
+    for (int m = 0; m < 2; m++) for (int n = 0; n < 3; n++) for (int i = 0; i < 16; i++) acc[m][n][i] = 0.f;
+    const int r32 = lane & 31, h = lane >> 5, hc = wave & 1, bd = wave >> 1;
+    const int abase = (hc * 64 + r32) * 128 + ((h ^ ((r32 >> 1) & 7)) << 4);
+    rsrc_t wr = make_rsrc(wsrc, 216 * 16384);
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int it = 0; it < iters; it++) {
+        if (MODE == 2) {
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                dma16_buf(wr, lane * 16, ((it % 216) * 16 + wave * 4 + j) * 1024, lds + 78848 + (wave * 4 + j) * 1024 * 0);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (MODE > 0) {
+                const int sl = it & 1;
+                const int px = (it * 7 + u * 3) % 58;                       // sliding pixel window like the taps
+#pragma unroll
+                for (int m = 0; m < 2; m++)
+                    a[m] = *reinterpret_cast<const bf16x8 *>(lds + (abase ^ (u << 5)) + sl * 16384 + m * 4096);
+#pragma unroll
+                for (int n = 0; n < 3; n++) {
+                    const int sp = (px + n * 32 + r32) % 90;
+                    b[n] = *reinterpret_cast<const bf16x8 *>(lds + 32768 + bd * 23040 + sp * 256 +
+                                                               ((((sp & 15) ^ h) << 4) ^ ((sl * 8 + u * 2) << 4)));
+                }
+            }
+#pragma unroll
+            for (int m = 0; m < 2; m++)
+#pragma unroll
+                for (int n = 0; n < 3; n++) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m], b[n], acc[m][n], 0, 0, 0);
+        }
+    }
+    float t = 0.f;
+    for (int m = 0; m < 2; m++) for (int n = 0; n < 3; n++) for (int i = 0; i < 16; i++) t += acc[m][n][i];
+    if (t == 123.456f) out[0] = t;
+    if (blockIdx.x == 0 && tid == 0) {       // core cycles and 100 MHz ticks of the loop -> clock under load
+        out[1] = (float)(__builtin_amdgcn_s_memtime() - c0);
+        out[2] = (float)(__builtin_amdgcn_s_memrealtime() - r0);
+    }
+}
+}  // namespace
+
+// the same bare loop on v_mfma_f32_16x16x32_bf16 (24 accumulators of 4 registers: the same 96 x 64
+// output tile per wave, the same FLOPs per iteration): which shape the chip clocks higher on
+namespace {
+template <int ORDER>        // 0: pixel tile outer, weight tile inner (the kernels' order: B operand constant over 4 MFMAs); 1: weight tile outer (A constant over 6)
+__global__ __launch_bounds__(256, 2) void k_mfma_probe16(const uint32_t *seed, float *out, int iters)
+{
+    const int tid = threadIdx.x, lane = tid & 63;
+    uint32_t s = seed[lane] + blockIdx.x * 2654435761u + tid * 40503u;
+    auto rnd = [&]() { s = s * 1664525u + 1013904223u; return s; };
+    bf16x8 a[4], b[6];
+    for (int i = 0; i < 8; i++) {
+        for (int m = 0; m < 4; m++) a[m][i] = (__bf16)(((int)(rnd() >> 9) % 2048 - 1024) * (1.0f / 1024.0f));
+        for (int n = 0; n < 6; n++) {
+            const float v = ((int)(rnd() >> 9) % 2048 - 1024) * (1.0f / 1024.0f);
+            b[n][i] = (__bf16)(v > 0.f ? v : 0.f);
+        }
+    }
+    f32x4 acc[4][6];
+    for (int m = 0; m < 4; m++) for (int n = 0; n < 6; n++) for (int i = 0; i < 4; i++) acc[m][n][i] = 0.f;
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            if (ORDER == 0) {
+#pragma unroll
+                for (int n = 0; n < 6; n++)
+#pragma unroll
+                    for (int m = 0; m < 4; m++) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m], b[n], acc[m][n], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int m = 0; m < 4; m++)
+#pragma unroll
+                    for (int n = 0; n < 6; n++) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m], b[n], acc[m][n], 0, 0, 0);
+            }
+        }
+    }
+    float t = 0.f;
+    for (int m = 0; m < 4; m++) for (int n = 0; n < 6; n++) for (int i = 0; i < 4; i++) t += acc[m][n][i];
+    if (t == 123.456f) out[0] = t;
+    if (blockIdx.x == 0 && tid == 0) {
+        out[1] = (float)(__builtin_amdgcn_s_memtime() - c0);
+        out[2] = (float)(__builtin_amdgcn_s_memrealtime() - r0);
+    }
+}
+}  // namespace
+
+// Steady-state loop probe (timing only, no barriers, results meaningless): what the trunk's main loop sustains as a
+// function of the wave tile.  MT = weight tiles per wave: 4 = the product kernel's 64 channels x 96 pixels at two waves
+// per SIMD (2 boards per 256-thread workgroup, 2 workgroups per CU); 8 = 128 channels x 96 pixels, ONE wave per SIMD,
+// a wave owns a whole board (4 boards per workgroup, one workgroup per CU): 14 fragment reads per 48 MFMAs instead of
+// 10 per 24, half the weight stream per board, no arbitration between waves.  One loop iteration = one tap = 4 K-steps
+// of 32 channels = 2 weight stages; fragments double-buffered by K-step, 4 LDS-DMA pieces per wave and stage, the
+// kernel's swizzled addresses (conflict-free).
+namespace {
+template <int MT, int WPS, bool AASM = false>
+__global__ __launch_bounds__(256, WPS) void k_loop_probe(const uint32_t *seed, const uint8_t *wsrc, float *out, int taps)
+{
+    constexpr int NBP = MT == 4 ? 2 : 4, ACT0 = 2 * WBUF_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wb_ = MT == 4 ? wave >> 1 : wave, hc = MT == 4 ? wave & 1 : 0;
+    const int r16 = lane & 15, q = lane >> 4;
+    uint32_t s = seed[lane] + blockIdx.x * 2654435761u + tid * 40503u;
+    auto rnd = [&]() { s = s * 1664525u + 1013904223u; return s; };
+    for (int i = tid; i < (ACT0 + NBP * ACT_BYTES) / 4; i += 256) {
+        const uint32_t r = rnd();
+        const float a = ((int)((r >> 8) & 2047) - 1024) * (1.0f / 1024.0f), b = ((int)((r >> 20) & 2047) - 1024) * (1.0f / 1024.0f);
+        uint32_t w = pack_bf16x2(a, b);
+        if (i >= ACT0 / 4) w = relu_bf16x2(w);
+        *(XQ_AS3 uint32_t *)(uint32_t)(i * 4) = w;
+    }
+    __syncthreads();
+    const int act_off = ACT0 + wb_ * ACT_BYTES;
+    const int abase = (hc * 64 + r16) * 128 + ((q ^ ((r16 >> 1) & 7)) << 4);
+    const int q4 = (((q & 1) << 3) | (q >> 1)) << 4;
+    const rsrc_t wr = make_rsrc(wsrc, 216 * 16384);
+    const int voff = (lane >> 3) * 256 + (((lane & 7) ^ (lane >> 4)) << 4);
+    f32x4 acc[AASM ? 1 : MT][6];
+    if constexpr (AASM) {
+        XQ_AGPR_ALL();
+        const f32x4 z4 = f32x4{ 0.f, 0.f, 0.f, 0.f };
+        aset_all(std::make_integer_sequence<int, MT * 6>{}, z4);
+    } else {
+#pragma unroll
+        for (int m = 0; m < MT; m++)
+#pragma unroll
+            for (int n = 0; n < 6; n++) { const float z = (float)(rnd() & 1023) * 1e-3f; acc[m][n] = f32x4{ z, z + 1.f, z + 2.f, z + 3.f }; }
+    }
+    bf16x8 fa[2][MT], fb[2][6];
+    auto row_addr = [&](int tap) {      // this lane's activation row for pixel tile 0 at this tap (tile n: + n * 4096, wrapped)
+        const int off = (tap / 3 - 1) * 9 + (tap % 3 - 1);
+        int sp = r16 + off;
+        sp = sp < 0 ? sp + 10 : sp;
+        return act_off + sp * 256 + ((((sp & 7) << 4)) ^ q4);
+    };
+    int as = row_addr(0);
+#pragma unroll
+    for (int m = 0; m < MT; m++) fa[0][m] = lds_ld128(abase + m * 2048);
+#pragma unroll
+    for (int n = 0; n < 6; n++) fb[0][n] = lds_ld128(as + (n < 5 ? n : 4) * 4096);
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int t = 0; t < taps; t++) {
+        const int tap = t % 9;
+        int asn = row_addr(tap == 8 ? 0 : tap + 1);
+        asm volatile("" : "+v"(asn));
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) {
+            const int sl = ks >> 1, kk = ks & 1, cur = ks & 1;
+#pragma unroll
+            for (int n = 0; n < 6; n++) {
+                // next K-step's fragments
+                const int a_next = ks < 3 ? as : asn;
+                fb[cur ^ 1][n] = lds_ld128((a_next ^ (((ks + 1) & 3) << 5)) + (n < 5 ? n : 4) * 4096);
+                constexpr int APT = (MT + 5) / 6 + (MT % 6 && MT > 6 ? 0 : 0);       // A fragments fetched per pixel tile
+                for (int j = 0; j < 2; j++) {
+                    const int m = n * ((MT + 5) / 6) + j;
+                    if (j < (MT + 5) / 6 && m < MT) {
+                        if (kk == 0) fa[cur ^ 1][m] = lds_ld128((abase ^ (1 << 6)) + sl * WBUF_BYTES + m * 2048);
+                        else fa[cur ^ 1][m] = lds_ld128(abase + (sl ^ 1) * WBUF_BYTES + m * 2048);
+                    }
+                }
+                (void)APT;
+                if (kk == 1 && n >= 1 && n < 5) {
+                    const int g = (t * 2 + sl + 2) % 216;
+                    dma16_buf_abs(wr, voff, g * 16384 + (wave * 4 + n - 1) * 1024, sl * WBUF_BYTES + (wave * 4 + n - 1) * 1024);
+                }
+                if constexpr (AASM) {
+                    // (asm MFMAs are invisible to sched_group_barrier: a tile's reads / DMA piece are pinned in front of its MFMAs)
+                    __builtin_amdgcn_sched_barrier(0);
+                    switch (n) {
+                    case 0: amfma_col<0>(std::make_integer_sequence<int, MT>{}, fa[cur], fb[cur][0]); break;
+                    case 1: amfma_col<1>(std::make_integer_sequence<int, MT>{}, fa[cur], fb[cur][1]); break;
+                    case 2: amfma_col<2>(std::make_integer_sequence<int, MT>{}, fa[cur], fb[cur][2]); break;
+                    case 3: amfma_col<3>(std::make_integer_sequence<int, MT>{}, fa[cur], fb[cur][3]); break;
+                    case 4: amfma_col<4>(std::make_integer_sequence<int, MT>{}, fa[cur], fb[cur][4]); break;
+                    default: amfma_col<5>(std::make_integer_sequence<int, MT>{}, fa[cur], fb[cur][5]); break;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                } else {
+#pragma unroll
+                for (int m = 0; m < MT; m++)
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[cur][m], fb[cur][n], acc[m][n], 0, 0, 0);
+                // issue order inside the tile: one read per MFMA gap up front, the DMA piece behind the second MFMA
+                constexpr int NRD = 1 + (MT + 5) / 6;
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, NRD - 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (kk == 1 && n >= 1 && n < 5) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, MT - 2, 0);
+                }
+            }
+        }
+        as = asn;
+    }
+    float tsum = 0.f;
+    if constexpr (AASM) {
+        asm volatile("s_nop 15\n\ts_nop 15");                       // MFMA results -> v_accvgpr_read: no interlock for asm
+        f32x4 t4 = aget<0>() + aget<MT * 6 - 1>();
+        tsum = t4[0] + t4[1] + t4[2] + t4[3];
+    } else {
+#pragma unroll
+    for (int m = 0; m < MT; m++)
+#pragma unroll
+        for (int n = 0; n < 6; n++)
+            for (int i = 0; i < 4; i++) tsum += acc[m][n][i];
+    }
+    if (tsum == 123.456f) out[0] = tsum;
+    if (blockIdx.x == 0 && tid == 0) {
+        out[1] = (float)(__builtin_amdgcn_s_memtime() - c0);
+        out[2] = (float)(__builtin_amdgcn_s_memrealtime() - r0);
+    }
+}
+}  // namespace
+
+extern "C" int xq_mfma_probe(void *stream, const void *seed64_dev, const void *weights_dev, void *out_dev, int n_workgroups,
+                             int iters, int mode)
+{
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (mode >= 20 && mode <= 22) {       // steady-state loop probes: 20 = 64 x 96 wave tile, 2 waves per SIMD; 21 = 128 x 96, one wave per SIMD
+        const int lds = mode == 20 ? 2 * WBUF_BYTES + 2 * ACT_BYTES : 2 * WBUF_BYTES + 4 * ACT_BYTES;
+        if (mode == 20) {
+            if (int rc = tower_lds_opt_in<&k_loop_probe<4, 2>>(lds)) return rc;
+            hipLaunchKernelGGL((k_loop_probe<4, 2>), dim3(n_workgroups), dim3(256), lds, st, (const uint32_t *)seed64_dev, (const uint8_t *)weights_dev, (float *)out_dev, iters);
+        } else if (mode == 21) {
+            if (int rc = tower_lds_opt_in<&k_loop_probe<8, 1>>(lds)) return rc;
+            hipLaunchKernelGGL((k_loop_probe<8, 1>), dim3(n_workgroups), dim3(256), lds, st, (const uint32_t *)seed64_dev, (const uint8_t *)weights_dev, (float *)out_dev, iters);
+        } else {                            // 22: the same with the accumulators on literal AGPRs (asm MFMAs)
+            if (int rc = tower_lds_opt_in<&k_loop_probe<8, 1, true>>(lds)) return rc;
+            hipLaunchKernelGGL((k_loop_probe<8, 1, true>), dim3(n_workgroups), dim3(256), lds, st, (const uint32_t *)seed64_dev, (const uint8_t *)weights_dev, (float *)out_dev, iters);
+        }
+        return hipGetLastError() == hipSuccess ? 0 : XQ_E_HIP;
+    }
+    if (mode == 16) {       // 48 MFMAs of 16x16x32 per iteration = the FLOPs of 24 of 32x32x16
+        hipLaunchKernelGGL(k_mfma_probe16<0>, dim3(n_workgroups), dim3(256), 0, st, (const uint32_t *)seed64_dev, (float *)out_dev, iters);
+        return hipGetLastError() == hipSuccess ? 0 : XQ_E_HIP;
+    }
+    if (mode == 17) {       // the same with the weight tile in the outer loop
+        hipLaunchKernelGGL(k_mfma_probe16<1>, dim3(n_workgroups), dim3(256), 0, st, (const uint32_t *)seed64_dev, (float *)out_dev, iters);
+        return hipGetLastError() == hipSuccess ? 0 : XQ_E_HIP;
+    }
+    const int lds_bytes = mode ? 80128 : 0;
+    if (mode == 0) hipLaunchKernelGGL(k_mfma_probe<0>, dim3(n_workgroups), dim3(256), 0, st, (const uint32_t *)seed64_dev, (const uint8_t *)weights_dev, (float *)out_dev, iters);
+    else {
+        const void *f = mode == 1 ? reinterpret_cast<const void *>(&k_mfma_probe<1>) : reinterpret_cast<const void *>(&k_mfma_probe<2>);
+        if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess) return XQ_E_HIP;
+        if (mode == 1) hipLaunchKernelGGL(k_mfma_probe<1>, dim3(n_workgroups), dim3(256), lds_bytes, st, (const uint32_t *)seed64_dev, (const uint8_t *)weights_dev, (float *)out_dev, iters);
+        else hipLaunchKernelGGL(k_mfma_probe<2>, dim3(n_workgroups), dim3(256), lds_bytes, st, (const uint32_t *)seed64_dev, (const uint8_t *)weights_dev, (float *)out_dev, iters);
+    }
+    return hipGetLastError() == hipSuccess ? 0 : XQ_E_HIP;
+}

@@ -227,9 +227,10 @@ def test_bf16_games_against_fp32_games(L):
     print("bf16 vs fp32 games: first-divergence ply histogram (index = ply, last = never within %d plies): %s; "
           "identical through ply 0: %.3f, through 8 plies: %.3f, whole %d plies: %.3f; visit-vector agreement on "
           "common positions: %.4f" % (P, hist.tolist(), (first > 0).mean(), (first >= 8).mean(), P, (first >= P).mean(), agree))
-    assert (first > 0).mean() >= 0.30                # FLOORS TO BE SET FROM THE FIRST MEASUREMENT
-    assert (first >= 8).mean() >= 0.02
-    assert agree >= 0.50
+    # measured on MI355X (round 3): through ply 0 1.000, through 8 plies 0.727, all 24 plies 0.363, agreement 0.959
+    assert (first > 0).mean() >= 0.98
+    assert (first >= 8).mean() >= 0.60
+    assert agree >= 0.93
     # outcome-level statistics are indistinguishable: both play ~uniform random-init games to the cap
     assert abs(float(a.n_plies.mean()) - float(b.n_plies.mean())) < 0.5
 

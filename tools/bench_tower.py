@@ -38,15 +38,13 @@ def timeit(fn, it=20):
 
 
 fl = 2.0 * G * 90 * (16 * 9 * 128 + 2 * blocks * 128 * 9 * 128 + 128 * 40)
-NAMES = {0: "k_tower (32x32x16)", 1: "k_tower16 (16x16x32, round 1)", 2: "k_tower16b (16x16x32, round 2)",
-         3: "k_tower16b with the skip connection on the VALU (comparison)"}
-NAMES[9] = "k_tower16b, 4 boards per 512-thread workgroup sharing one weight stream (experiment)"
-NAMES[10] = "k_tower16s, 4 boards per workgroup in two groups two stage steps apart (experiment)"
-for variant in ((1, 2, 10, 9, 2, 10, 9, 2, 10) if os.environ.get("XQ_BT_SHORT") is None else (2, 10, 2, 10)):
+NAMES = {0: "k_tower (32x32x16)", 36: "k_tower16b, 2 boards per workgroup", 39: "k_tower16b, 4 boards per workgroup",
+         50: "k_tower1w (one wave per SIMD; probes build)"}
+for variant in (0, 36, 39):
     L.xq_tower_set_variant(variant)
     ms = timeit(lambda: L.xq_tower_nhwc_bf16(*args, None, None))
     print("%s G=%d blocks=%d: %.3f ms  %.1f TFLOP/s" % (NAMES[variant], G, blocks, ms, fl / ms / 1e9))
-variant = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+variant = int(sys.argv[3]) if len(sys.argv) > 3 else 36
 L.xq_tower_set_variant(variant)
 print("stamps: variant %d" % variant)
 
@@ -54,22 +52,17 @@ fn = L.xq_tower_debug_stamps
 fn.argtypes = [C.c_void_p] * 9 + [C.c_int, C.c_int, C.c_void_p]
 nwg = (G + 1) // 2
 stamps = torch.zeros(nwg * 64, dtype=torch.int64, device="cuda")
-if variant in (1, 2) and os.environ.get("XQ_BT_SHORT") is None:
-    # ablation builds (results are wrong on purpose): what the weight refills / stage barriers / tap arithmetic cost
-    abl = (((1, "stamped build"), (7, "no weight refills"), (4, "no stage barriers"), (5, "neither"),
-            (6, "no per-tap address arithmetic")) if variant == 1 else
-           ((2, "stamped build"), (12, "no weight refills"), (13, "no stage barriers"), (14, "no per-tap address arithmetic"),
-            (15, "weight refills issued but never waited for"), (16, "OPTION s_setprio 3 in epilogues (results valid)"),
-            (17, "OPTION one filler per MFMA gap (results valid)"), (18, "no refills, no tap arithmetic"),
-            (19, "comparison: skip connection on the VALU (results valid)"),
-            (2, "stamped build again")))
+if variant in (36, 39) and os.environ.get("XQ_BT_SHORT") is None:
+    # ablation builds (results are wrong on purpose; probes library): what the weight refills / stage barriers cost
+    abl = ((36, "stamped build"), (30, "no weight refills"), (31, "no stage barriers"), (36, "stamped build again")) if variant == 36 else (
+        (39, "stamped build"), (41, "no stage barriers"), (43, "no stage barriers, no weight refills"), (39, "stamped build again"))
     for v, name in abl:
         L.xq_tower_set_variant(v)
         if fn(*args, stamps.data_ptr()) != 0:
-            print("%s %s: not in this library (build with XQ_TOWER_PROBES=1)" % (NAMES[variant].split()[0], name))
+            print("%s, %s: not in this library (build with XQ_TOWER_PROBES=1)" % (NAMES[variant], name))
             continue
         ms = timeit(lambda: fn(*args, stamps.data_ptr()), it=10)
-        print("%s %s: %.3f ms" % (NAMES[variant].split()[0], name, ms))
+        print("%s, %s: %.3f ms" % (NAMES[variant], name, ms))
     L.xq_tower_set_variant(variant)
 for _ in range(2):
     fn(*args, stamps.data_ptr())

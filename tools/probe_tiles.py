@@ -1,7 +1,7 @@
-"""Power probe (run on the GPU box): k_tower16s against a build whose last two waves leave out their sixth pixel tile
-(23 instead of 24 pixel tiles of MFMA work per 4 boards; wrong results, timing only).  The critical path does not
-change (the other six waves still run six tiles), so any gain is the chip answering less matrix work per board with
-a higher clock."""
+"""Trunk builds interleaved in one process through the stamp entry point (run on the GPU box): wall time, workgroup
+cycles, the clock the chip holds, and (XQ_PROBE_PHASES=1) the cycles of every phase.  usage: probe_tiles.py V1 V2 ...
+(36 / 39 = k_tower16b with 2 / 4 boards per workgroup, 0 = 32x32x16; 50, 30, 31, 41, 43 need a library built with
+XQ_TOWER_PROBES=1)."""
 import ctypes as C
 import os
 import sys
@@ -25,14 +25,15 @@ P = torch.empty(G, 2880, device="cuda", dtype=torch.bfloat16)
 V = torch.empty(G, 720, device="cuda", dtype=torch.bfloat16)
 args = (st, planes.data_ptr(), inet.hip_w[0].data_ptr(), inet.hip_wt.data_ptr(), inet.hip_bt.data_ptr(),
         inet.hip_hw.data_ptr(), inet.hip_hb.data_ptr(), P.data_ptr(), V.data_ptr(), G, blocks)
+fl = 2.0 * G * 90 * (16 * 9 * 128 + 2 * blocks * 128 * 9 * 128 + 128 * 40)
 fn = L.xq_tower_debug_stamps
 fn.argtypes = [C.c_void_p] * 9 + [C.c_int, C.c_int, C.c_void_p]
 stamps = torch.zeros((G + 1) // 2 * 64, dtype=torch.int64, device="cuda")
-names = {33: "k_tower16b<PAIR>, skip connection on the VALU",
-         29: "k_tower16b<PAIR>, 4 boards in lock-step", 9: "k_tower16b, 4 boards in lock-step",
-         30: "k_tower16b<PAIR>, no weight refills", 31: "k_tower16b<PAIR>, no stage barriers", 32: "k_tower16b<PAIR>, one filler per MFMA gap",
-         2: "k_tower16b", 8: "k_tower16b, 16-byte epilogue stores", 10: "k_tower16s", 24: "k_tower16s, 16-byte epilogue stores", 25: "k_tower16s, 16-byte stores, s_setprio 3", 11: "k_tower16s, 23 of 24 pixel tiles", 20: "k_tower16s, s_setprio 3 in epilogues",}
-for variant in [int(v) for v in sys.argv[1:]] or (2, 10, 11, 2, 10, 11, 10, 11):
+names = {36: "k_tower16b, 2 boards per workgroup", 39: "k_tower16b, 4 boards per workgroup (lock-step)", 0: "k_tower (32x32x16)",
+         50: "k_tower1w: one wave per SIMD, 128 x 96 tile, 4 boards/WG",
+         30: "k_tower16b<2>, no weight refills (probe)", 31: "k_tower16b<2>, no stage barriers (probe)",
+         41: "k_tower16b<4>, NO stage barriers (probe)", 43: "k_tower16b<4>, no barriers, no refills (probe)"}
+for variant in [int(v) for v in sys.argv[1:]] or (36, 39, 50, 36, 39, 50):
     L.xq_tower_set_variant(variant)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     if fn(*args, stamps.data_ptr()) != 0:
@@ -48,19 +49,15 @@ for variant in [int(v) for v in sys.argv[1:]] or (2, 10, 11, 2, 10, 11, 10, 11):
     s = stamps.cpu().numpy().reshape(-1, 64).astype(np.float64)
     s = s[s[:, 61] > 0]
     tot, rt = s[:, 61] - s[:, 0], s[:, 63] - s[:, 62]
-    print("%-36s %.3f ms, workgroup %d cycles, clock %.3f GHz" % (names[variant], e0.elapsed_time(e1) / 20, np.median(tot),
-                                                                 np.median(tot / rt * 0.1)), flush=True)
-    if variant in (10, 20, 24, 25) and s[:, 30].max() > 0:
-        for grp, o in (("lead", 0), ("lag", 12)):
-            for layer in (2, 3):
-                f = s[:, 30 + o + 6 * (layer - 2):30 + o + 6 * (layer - 2) + 6]
-                d = np.median(np.diff(f[:, :5], axis=1), axis=0)
-                print("    %s group, layer %d: first half %d (issued after %d), wait at #18 %d, second half %d, wait at #19 %d cycles"
-                      % (grp, layer, d[0], np.median(f[:, 5] - f[:, 0]), d[1], d[2], d[3]))
-    if s[:, 54].max() > 0:      # slots 54 / 55 / 56: lead group's arrival at, release from stage barrier 8 of layer 2, arrival at 9; 57..59: lag group
-        print("    layer 2, stage barrier 8: lead group waits %d, lag group waits %d cycles; arrival to next arrival: lead %d, lag %d; "
-              "lead arrives %d cycles before lag" % (np.median(s[:, 55] - s[:, 54]), np.median(s[:, 58] - s[:, 57]),
-                                                      np.median(s[:, 56] - s[:, 54]), np.median(s[:, 59] - s[:, 57]),
-                                                      np.median(s[:, 57] - s[:, 54])))
+    ms = e0.elapsed_time(e1) / 20
+    print("%-52s %.3f ms = %.3f of 2.5 PFLOP/s, workgroup %d cycles, clock %.3f GHz" % (
+        names.get(variant, "variant %d" % variant), ms, fl / ms / 1e9 / 2500.0, np.median(tot), np.median(tot / rt * 0.1)), flush=True)
+    if os.environ.get("XQ_PROBE_PHASES"):
+        nl = 2 * blocks
+        main = [int(np.median(s[:, 3 + 2 * l] - s[:, 2 + 2 * l])) for l in range(nl)]
+        epi = [int(np.median(s[:, 4 + 2 * l] - s[:, 3 + 2 * l])) for l in range(nl)]
+        print("    input conv %d + epilogue %d | main loops %s | epilogues %s | heads %d + stores %d" % (
+            np.median(s[:, 1] - s[:, 0]), np.median(s[:, 2] - s[:, 1]), main, epi, np.median(s[:, 60] - s[:, 2 + 2 * nl]),
+            np.median(s[:, 61] - s[:, 60])))
     stamps.zero_()
-L.xq_tower_set_variant(36)
+L.xq_tower_set_variant(-1)

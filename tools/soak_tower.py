@@ -1,5 +1,6 @@
 """Soak test of the trunk kernel (run on the GPU box): many launches on fresh buffers and changing
-sizes, the 16x16x32 build against the 32x32x16 build and against itself — any difference beyond bf16
+sizes, a 16x16x32 build (36 / 39 = 2 / 4 boards per workgroup, -1 = the library's choice) against the 32x32x16 build (or
+against another build: third argument) and against itself — any difference beyond bf16
 rounding noise would be a synchronisation bug (both kernels are deterministic)."""
 import os
 import sys
@@ -13,7 +14,7 @@ from chinesechessai_amd.neural_network import ChessNet, InferenceNet
 L = _lib.lib()
 st = torch.cuda.current_stream().cuda_stream
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
-va = int(sys.argv[2]) if len(sys.argv) > 2 else 36       # build under test (run twice) ...
+va = int(sys.argv[2]) if len(sys.argv) > 2 else -1       # build under test (run twice) ...
 vb = int(sys.argv[3]) if len(sys.argv) > 3 else 0        # ... and the build it is compared with
 t0, it, worst, nondet = time.time(), 0, 0.0, 0
 last_print = t0
@@ -47,7 +48,7 @@ while time.time() - t0 < budget:
     if time.time() - last_print > 60:                      # (a silent GPU command is taken to be hung after 7 minutes)
         last_print = time.time()
         print("  ... %d nets, worst %.4g, mismatches %d" % (it, worst, nondet), flush=True)
-L.xq_tower_set_variant(36)
+L.xq_tower_set_variant(-1)
 print("soak (build %d vs build %d): %d nets, worst relative difference between the two builds %.4g, run-to-run mismatches %d"
       % (va, vb, it, worst, nondet))
 assert nondet == 0

@@ -10,7 +10,7 @@ from chinesechessai_amd.neural_network import ChessNet, InferenceNet
 
 L = _lib.lib()
 G, blocks = int(os.environ.get("XQ_PROBE_G", "16384")), 6
-variants = [int(v) for v in sys.argv[1:]] or [8, 24, 8, 24]
+variants = [int(v) for v in sys.argv[1:]] or [36, 39, 36, 39]
 st = torch.cuda.current_stream().cuda_stream
 torch.manual_seed(0)
 inet = InferenceNet(ChessNet(num_blocks=blocks).eval().cuda())
@@ -45,4 +45,4 @@ for v in variants:
     ms = e0.elapsed_time(e1) / 20
     same = torch.equal(P, P0) and torch.equal(V, V0)
     print("variant %2d: %.3f ms  %.1f TFLOP/s  %s" % (v, ms, fl / ms / 1e9, "== default build" if same else "differs from the default build"), flush=True)
-L.xq_tower_set_variant(36)
+L.xq_tower_set_variant(-1)
