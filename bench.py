@@ -74,7 +74,7 @@ def pmc_traffic(kernel, G, S, blocks, fetch_factor=1.0):
     correction, MI355X_MICROARCH.md); (None, None) for configs that were not profiled."""
     if not (G == 16384 and S == 50 and blocks == 6):
         return None, None
-    for name in ("r02c_pmc_kernels.json", "r02b_pmc_kernels.json", "r02_pmc_kernels.json", "r01g_pmc_kernels.json", "r01f_pmc_kernels.json", "r01d_pmc_kernels.json"):
+    for name in ("r03_pmc_kernels.json", "r02c_pmc_kernels.json", "r02b_pmc_kernels.json", "r02_pmc_kernels.json", "r01g_pmc_kernels.json", "r01f_pmc_kernels.json", "r01d_pmc_kernels.json"):
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
             doc = json.load(open(path))
