@@ -431,7 +431,7 @@ def run_rank(args):
     # with --warmup 0: code-object load (one forward on the full-size buffers),
     # RCCL communicator set-up (one tiny all-gather)
     ev.bind(eng)
-    ev.evaluate(eng)
+    ev.inet(ev.x, out_logits=ev.logits, out_values=ev.values)      # (all rows, no row map: a full-size launch of every kernel)
     if use_dist:
         xd.all_gather_records(torch.zeros(xd.RECORD_BYTES, dtype=torch.uint8, device="cuda"))
     torch.cuda.synchronize()

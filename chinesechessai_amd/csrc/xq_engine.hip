@@ -677,24 +677,49 @@ __global__ __launch_bounds__(64) void k_hashnet(Eng E, int salt)
 constexpr int ROW_HIST = 65536;
 __global__ __launch_bounds__(1024) void k_assign_rows(Eng E, int n_slots, unsigned seq)
 {
-    __shared__ int wsum[16];
+    // 16 chunks of 1,024 slots per pass: every thread first loads its 16 flags (independent loads: one memory latency
+    // for the pass instead of one per chunk), then one wave scans the 16 x 16 per-(chunk, wave) counts
+    constexpr int CH = 16;
+    __shared__ int cnt[CH * 16], off[CH * 16 + 1];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int base = 0;
-    for (int start = 0; start < n_slots; start += 1024) {
-        const int slot = start + tid;
-        const bool pending = slot < n_slots && E.leaf_node[slot] != LEAF_NONE && !E.gs[slot / E.leaf_slots].done;
-        const unsigned long long m = __ballot(pending);
-        if (lane == 0) wsum[wave] = __popcll(m);
-        __syncthreads();
-        int off = base, total = 0;
+    for (int start = 0; start < n_slots; start += CH * 1024) {
+        bool pend[CH];
+        unsigned long long mask[CH];
 #pragma unroll
-        for (int w = 0; w < 16; w++) { const int c = wsum[w]; off += w < wave ? c : 0; total += c; }
-        if (slot < n_slots) {
-            const int row = pending ? off + __popcll(m & ((1ull << lane) - 1ull)) : -1;
-            E.leaf_row[slot] = row;
-            if (pending) E.row_src[row] = slot;
+        for (int c = 0; c < CH; c++) {
+            const int slot = start + c * 1024 + tid;
+            pend[c] = slot < n_slots && E.leaf_node[slot] != LEAF_NONE && !E.gs[slot / E.leaf_slots].done;
         }
-        base += total;
+#pragma unroll
+        for (int c = 0; c < CH; c++) {
+            mask[c] = __ballot(pend[c]);
+            if (lane == 0) cnt[c * 16 + wave] = __popcll(mask[c]);
+        }
+        __syncthreads();
+        if (wave == 0) {                                  // exclusive scan of the 256 counts in (chunk, wave) order
+            int v[4], sum = 0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) { v[i] = cnt[lane * 4 + i]; sum += v[i]; }
+            int incl = sum;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d, 64); if (lane >= d) incl += o; }
+            int run = incl - sum;
+#pragma unroll
+            for (int i = 0; i < 4; i++) { off[lane * 4 + i] = run; run += v[i]; }
+            if (lane == 63) off[CH * 16] = incl;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < CH; c++) {
+            const int slot = start + c * 1024 + tid;
+            if (slot < n_slots) {
+                const int row = pend[c] ? base + off[c * 16 + wave] + __popcll(mask[c] & ((1ull << lane) - 1ull)) : -1;
+                E.leaf_row[slot] = row;
+                if (pend[c]) E.row_src[row] = slot;
+            }
+        }
+        base += off[CH * 16];
         __syncthreads();
     }
     if (tid == 0) { E.row_count[0] = base; E.row_hist[seq & (ROW_HIST - 1)] = base; }
