@@ -824,6 +824,9 @@ static int launch_tower(void *stream, const void *planes, const void *w1, const 
     else if (v == 0) XQ_TOWER_LAUNCH((k_tower<STAMP>), grid2, 256, LDS_BYTES);
 #if XQ_TOWER_PROBES
     else if (v == 50) XQ_TOWER_LAUNCH((k_tower1w<STAMP>), grid4, 256, LDS_BYTES1W);                   // one wave per SIMD (results valid)
+    else if (STAMP && v == 51) XQ_TOWER_LAUNCH((k_tower1w<true, 1>), grid4, 256, LDS_BYTES1W);       // ... no stage barriers (wrong results)
+    else if (STAMP && v == 52) XQ_TOWER_LAUNCH((k_tower1w<true, 3>), grid4, 256, LDS_BYTES1W);       // ... no barriers, no vmcnt waits
+    else if (STAMP && v == 53) XQ_TOWER_LAUNCH((k_tower1w<true, 7>), grid4, 256, LDS_BYTES1W);       // ... and no weight DMA
     else if (STAMP && (row_src || n_rows)) return XQ_E_INVALID;
     else if (STAMP && v == 30) XQ_TOWER_LAUNCH((k_tower16b<true, 1, 2>), grid2, 256, LDS_BYTES);     // no weight refills (wrong results)
     else if (STAMP && v == 31) XQ_TOWER_LAUNCH((k_tower16b<true, 2, 2>), grid2, 256, LDS_BYTES);     // no stage barriers

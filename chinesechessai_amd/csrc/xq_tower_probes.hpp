@@ -23,45 +23,72 @@ namespace {
 // Same LDS images, swizzles, channel deal (PAIR), weight-source permutation and accumulation order as
 // k_tower16b<PAIR>: the results are bit-identical to it.
 // ------------------------------------------------------------------------------------------
-// Accumulators named literally (a[4 t .. 4 t + 3] for tile t): hipcc keeps 192 accumulator registers in AGPRs only
-// with two to three v_accvgpr copies per MFMA in the loop (untied AGPR-form MFMAs rotated through staging tuples),
-// so the one-wave-per-SIMD builds issue their MFMAs as asm statements on fixed AGPRs.  The compiler never sees these
-// registers: XQ_AGPR_ALL (one statement, at kernel entry) makes it account for them in the kernel descriptor, and
-// every build is checked (ISA) for AGPR uses of its own.
+// The 192 accumulator registers have to live in AGPRs, and hipcc cannot keep them there by itself: for
+// __builtin_amdgcn_mfma_* it selects untied AGPR-form MFMAs and rotates the accumulators through staging tuples, two to
+// three v_accvgpr copies per MFMA in the loop.  So every MFMA, accumulator read / write and bias load is an asm statement
+// on LITERAL registers: tile t lives in a[4t : 4t + 3], the compiler never sees these registers; XQ_AGPR_ALL (one statement
+// at kernel entry) makes it account for them in the kernel descriptor.  This is an EXPERIMENT's contract, not a product's:
+// nothing stops hipcc from spilling its own values into the same registers when it runs out of VGPRs (it did as soon as
+// the kernel got a persistent outer loop), so every build is checked by an ISA scan - no compiler-generated AGPR use
+// before the last stage barrier, no VALU write directly in front of an asm MFMA that reads it.  The two compiler-tracked
+// forms were built and are slower: "+a" operands (hipcc then allocates the accumulators itself, the kernel sits at 256 +
+// 256 registers and the main loop takes 33.5 k cycles instead of 30.7 k; with the address variants hoisted 51 k, a few
+// scratch reloads in the loop each waiting vmcnt(0) behind the weight DMA), and physical-register constraints
+// ("+{a[0:3]}": the value has a VGPR class between the statements, 192 of them spill).
+// What hipcc does NOT do for an asm MFMA: insert the wait states a VALU-written source needs (amfma_guarded) or the ones
+// between an MFMA and a v_accvgpr_read of its result (s_nop block at the head of the epilogue).
 #define XQ_A8(b) "a" #b "0", "a" #b "1", "a" #b "2", "a" #b "3", "a" #b "4", "a" #b "5", "a" #b "6", "a" #b "7", "a" #b "8", "a" #b "9"
 #define XQ_AGPR_ALL() asm volatile("" ::: "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", XQ_A8(1), XQ_A8(2), XQ_A8(3), XQ_A8(4), \
     XQ_A8(5), XQ_A8(6), XQ_A8(7), XQ_A8(8), XQ_A8(9), XQ_A8(10), XQ_A8(11), XQ_A8(12), XQ_A8(13), XQ_A8(14), XQ_A8(15), XQ_A8(16), \
     XQ_A8(17), XQ_A8(18), "a190", "a191")
-template <int T> __device__ __forceinline__ void amfma(const bf16x8 &a, const bf16x8 &b)
+// (the f32x4 & parameter is the compiler-visible stand-in of the tile: unused by this form)
+template <int T> __device__ __forceinline__ void amfma(f32x4 &, const bf16x8 &a, const bf16x8 &b)
 {
     asm volatile("v_mfma_f32_16x16x32_bf16 a[%0:%1], %2, %3, a[%0:%1]" : : "n"(4 * T), "n"(4 * T + 3), "v"(a), "v"(b));
 }
-// the same behind two wait states: for operands the compiler may still be assembling with VALU moves right in front of
-// the statement (VALU write -> MFMA source read needs wait states that hipcc does not insert for an asm MFMA: a selector
-// built by v_perm / v_mov directly in front of its first MFMA was read stale)
-template <int T> __device__ __forceinline__ void amfma_guarded(const bf16x8 &a, const bf16x8 &b)
+template <int T> __device__ __forceinline__ void amfma_guarded(f32x4 &, const bf16x8 &a, const bf16x8 &b)
 {
     asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 a[%0:%1], %2, %3, a[%0:%1]" : : "n"(4 * T), "n"(4 * T + 3), "v"(a), "v"(b));
 }
-template <int T> __device__ __forceinline__ void aset(const f32x4 &v)          // a[4T .. 4T+3] = v
+template <int T> __device__ __forceinline__ void aset(f32x4 &, const f32x4 &v)          // a[4T .. 4T+3] = v
 {
     asm volatile("v_accvgpr_write_b32 a[%0], %4\n\tv_accvgpr_write_b32 a[%1], %5\n\tv_accvgpr_write_b32 a[%2], %6\n\tv_accvgpr_write_b32 a[%3], %7"
                  : : "n"(4 * T), "n"(4 * T + 1), "n"(4 * T + 2), "n"(4 * T + 3), "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
 }
-template <int T> __device__ __forceinline__ f32x4 aget()
+template <int T> __device__ __forceinline__ f32x4 aget(const f32x4 &)
 {
     float x0, x1, x2, x3;
     asm volatile("v_accvgpr_read_b32 %0, a[%4]\n\tv_accvgpr_read_b32 %1, a[%5]\n\tv_accvgpr_read_b32 %2, a[%6]\n\tv_accvgpr_read_b32 %3, a[%7]"
                  : "=v"(x0), "=v"(x1), "=v"(x2), "=v"(x3) : "n"(4 * T), "n"(4 * T + 1), "n"(4 * T + 2), "n"(4 * T + 3));
     return f32x4{ x0, x1, x2, x3 };
 }
-// compile-time loops over tiles (the tile index must be a constant expression for the asm templates)
-template <int... Ts> __device__ __forceinline__ void aset_all(std::integer_sequence<int, Ts...>, const f32x4 &v) { (aset<Ts>(v), ...); }
-template <int N0, int... Ms> __device__ __forceinline__ void amfma_col(std::integer_sequence<int, Ms...>, const bf16x8 *fa, const bf16x8 &fb)
+// a[4T .. 4T+3] = 16 bytes of LDS at addr + OFF, straight into the accumulator (a layer's bias as its start value, no VALU
+// instruction).  An asm load is outside hipcc's s_waitcnt bookkeeping: the caller waits with await_lds() before the
+// registers are used; the compiler's own counted waits stay correct (extra operations in the in-order LDS queue only make
+// them conservative).
+template <int T, int OFF> __device__ __forceinline__ void aload(f32x4 &, int addr)
 {
-    (amfma<Ms * 6 + N0>(fa[Ms], fb), ...);
+    asm volatile("ds_read_b128 a[%0:%1], %2 offset:%3" : : "n"(4 * T), "n"(4 * T + 3), "v"(addr), "n"(OFF) : "memory");
 }
+// compile-time loops over tiles
+template <int N0, int... Ms> __device__ __forceinline__ void amfma_col(std::integer_sequence<int, Ms...>, f32x4 *acc, const bf16x8 *fa, const bf16x8 &fb)
+{
+    (amfma<Ms * 6 + N0>(acc[Ms * 6 + N0], fa[Ms], fb), ...);
+}
+template <int... Ts> __device__ __forceinline__ void aset_all(std::integer_sequence<int, Ts...>, f32x4 *acc, const f32x4 &v) { (aset<Ts>(acc[Ts], v), ...); }
 
+// one MFMA of weight tile M on pixel tile n (n is a constant after unrolling: the switch folds away)
+template <int M> __device__ __forceinline__ void amfma_n(f32x4 *acc, int n, const bf16x8 &a, const bf16x8 &b)
+{
+    switch (n) {
+    case 0: amfma<M * 6 + 0>(acc[M * 6 + 0], a, b); break;
+    case 1: amfma<M * 6 + 1>(acc[M * 6 + 1], a, b); break;
+    case 2: amfma<M * 6 + 2>(acc[M * 6 + 2], a, b); break;
+    case 3: amfma<M * 6 + 3>(acc[M * 6 + 3], a, b); break;
+    case 4: amfma<M * 6 + 4>(acc[M * 6 + 4], a, b); break;
+    default: amfma<M * 6 + 5>(acc[M * 6 + 5], a, b); break;
+    }
+}
 
 #ifndef XQ_1W_DEBUG_WAIT
 #define XQ_1W_DEBUG_WAIT 0x0F74      // vmcnt(4); -DXQ_1W_DEBUG_WAIT=0x0070 drains everything at every stage barrier
@@ -69,9 +96,9 @@ template <int N0, int... Ms> __device__ __forceinline__ void amfma_col(std::inte
 constexpr int RING1W = 4;
 constexpr int LDS_BYTES1W = RING1W * WBUF_BYTES + 4 * ACT_BYTES + 256 + 2 * 512;
 
-template <int N0, int... Ms> __device__ __forceinline__ void aset_col(std::integer_sequence<int, Ms...>, const f32x4 *b)
+template <int N0, int... Ms> __device__ __forceinline__ void aset_col(std::integer_sequence<int, Ms...>, f32x4 *acc, const f32x4 *b)
 {
-    (aset<Ms * 6 + N0>(b[Ms]), ...);
+    (aset<Ms * 6 + N0>(acc[Ms * 6 + N0], b[Ms]), ...);
 }
 // two floats -> packed bf16 + ReLU without an asm statement (hipcc selects v_cvt_pk_bf16_f32 for the vector conversion and
 // can schedule it; the asm form of xq_mfma.hpp costs a boundary s_nop per use)
@@ -85,39 +112,33 @@ __device__ __forceinline__ uint32_t pack_relu_bf16x2(float a, float b)
     v = __builtin_elementwise_max(v, (s16x2_t){ 0, 0 });
     return *reinterpret_cast<const uint32_t *>(&v);
 }
-// a[4T .. 4T+3] = 16 bytes of LDS at addr + OFF: the accumulator's start value (a layer's bias) without a VALU instruction.
-// An asm load is outside hipcc's s_waitcnt bookkeeping: the caller waits with await_lds() before the registers are used
-// (the compiler's own counted waits stay correct: extra operations in the in-order LDS queue only make them conservative).
-template <int T, int OFF> __device__ __forceinline__ void aload(int addr)
-{
-    asm volatile("ds_read_b128 a[%0:%1], %2 offset:%3" : : "n"(4 * T), "n"(4 * T + 3), "v"(addr), "n"(OFF) : "memory");
-}
 __device__ __forceinline__ void await_lds() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 // epilogue of pixel tile N of channel pair J: the lane's 8 consecutive channels (tiles 2J, 2J + 1) -> bf16 -> ReLU -> 16 bytes
-template <int J, int N> __device__ __forceinline__ uint4 epi_get()
+template <int J, int N> __device__ __forceinline__ uint4 epi_get(const f32x4 *acc)
 {
-    const f32x4 v0 = aget<(2 * J) * 6 + N>(), v1 = aget<(2 * J + 1) * 6 + N>();
+    const f32x4 v0 = aget<(2 * J) * 6 + N>(acc[(2 * J) * 6 + N]), v1 = aget<(2 * J + 1) * 6 + N>(acc[(2 * J + 1) * 6 + N]);
     return make_uint4(pack_relu_bf16x2(v0[0], v0[1]), pack_relu_bf16x2(v0[2], v0[3]),
                       pack_relu_bf16x2(v1[0], v1[1]), pack_relu_bf16x2(v1[2], v1[3]));
 }
 // first half of a pair's epilogue: [x fragments in,] results out, next layer's bias into the accumulators
 template <int J, bool READ_X, int... Ns>
-__device__ __forceinline__ void epi_pair(std::integer_sequence<int, Ns...>, const int *sb, bool tail_ok, int lbq, bf16x8 *xf)
+__device__ __forceinline__ void epi_pair(std::integer_sequence<int, Ns...>, f32x4 *acc, const int *sb, bool tail_ok, int lbq, bf16x8 *xf)
 {
     if constexpr (READ_X) ((xf[Ns] = lds_ld128(sb[Ns] ^ (J << 5))), ...);          // the block input x: the chunk this lane overwrites
     uint4 pk[6];
-    ((pk[Ns] = epi_get<J, Ns>()), ...);
+    ((pk[Ns] = epi_get<J, Ns>(acc)), ...);
     ((Ns < 5 || tail_ok ? lds_st128(sb[Ns] ^ (J << 5), pk[Ns]) : (void)0), ...);
-    ((aload<(2 * J) * 6 + Ns, J * 128>(lbq), aload<(2 * J + 1) * 6 + Ns, J * 128 + 16>(lbq)), ...);
+    ((aload<(2 * J) * 6 + Ns, J * 128>(acc[(2 * J) * 6 + Ns], lbq), aload<(2 * J + 1) * 6 + Ns, J * 128 + 16>(acc[(2 * J + 1) * 6 + Ns], lbq)), ...);
 }
 // second half (first convolution of a block): + x through the matrix pipe, S . X with a 0/1 selector S
 template <int J, int... Ns>
-__device__ __forceinline__ void epi_skip(std::integer_sequence<int, Ns...>, const bf16x8 *sel, const bf16x8 *xf)
+__device__ __forceinline__ void epi_skip(std::integer_sequence<int, Ns...>, f32x4 *acc, const bf16x8 *sel, const bf16x8 *xf)
 {
-    ((amfma_guarded<(2 * J) * 6 + Ns>(sel[0], xf[Ns]), amfma_guarded<(2 * J + 1) * 6 + Ns>(sel[1], xf[Ns])), ...);
+    ((amfma_guarded<(2 * J) * 6 + Ns>(acc[(2 * J) * 6 + Ns], sel[0], xf[Ns]), amfma_guarded<(2 * J + 1) * 6 + Ns>(acc[(2 * J + 1) * 6 + Ns], sel[1], xf[Ns])), ...);
 }
 
-template <bool STAMP>
+// ABL (timing probes, wrong results): 1 = no stage barriers, 2 = no vmcnt wait in front of them, 4 = no weight DMA
+template <bool STAMP, int ABL = 0>
 __global__ __launch_bounds__(256, 1) void k_tower1w(TowerArgs A)
 {
     constexpr int NB = 4, PPW = 4;                                       // boards = waves, weight pieces per wave and stage
@@ -125,8 +146,10 @@ __global__ __launch_bounds__(256, 1) void k_tower1w(TowerArgs A)
     using seq8 = std::make_integer_sequence<int, 8>;
     using seq6 = std::make_integer_sequence<int, 6>;
 
+    bool stamping = true;                                              // stamps describe a workgroup's FIRST quad
     auto stamp = [&](int slot) {
         if constexpr (STAMP) {
+            if (!stamping) return;
             const unsigned long long t = __builtin_amdgcn_s_memtime();
             if (threadIdx.x == 0) A.stamps[(size_t)blockIdx.x * 64 + slot] = t;
             if (slot == 0 || slot == 61) {
@@ -137,21 +160,27 @@ __global__ __launch_bounds__(256, 1) void k_tower1w(TowerArgs A)
     };
     stamp(0);
     XQ_AGPR_ALL();
+    f32x4 acc[48];                                                     // stand-ins of the tiles: tile (mt, n) = acc[mt * 6 + n] lives in a[4t : 4t + 3]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     auto chan_row = [&](int mt, int i) { return (mt >> 1) * 32 + (i >> 2) * 8 + (mt & 1) * 4 + (i & 3); };
     int nrows = A.G;
     if (A.n_rows) { const int n = *A.n_rows; nrows = n < A.G ? n : A.G; }
-    if ((int)blockIdx.x * NB >= nrows) return;     // compaction: no row for this workgroup (uniform, before any barrier / DMA)
-    const int board = blockIdx.x * NB + wave;
-    const bool board_ok = board < nrows;
     const int act_off = ACT0 + wave * ACT_BYTES;
     const int r16 = lane & 15, q = lane >> 4;
+    const int pl_off = act_off + ACT_BYTES - PIX * 32;
+    const int nlayers = 2 * A.nblocks, nstages = nlayers * 18;
+    // (A persistent form - one workgroup per CU walking over its quads of boards, no launch gap, the next quad's planes
+    // prefetched - was built on this loop shape and dropped: with the outer loop hipcc runs out of VGPRs and spills into
+    // the literally named accumulators.)
+    const int quad = blockIdx.x;
+    if (quad * NB >= nrows) return;
+    {
+    const int board = quad * NB + wave;
+    const bool board_ok = board < nrows;
 
     // ---------------------------------------------------------------- input conv (16 -> 128)
-    const int pl_off = act_off + ACT_BYTES - PIX * 32;
     if (tid < 16) lds_st128(ZROW + tid * 16, make_uint4(0, 0, 0, 0));
-    const int nlayers = 2 * A.nblocks, nstages = nlayers * 18;
     if (wave == 1 && lane < 32 && nstages > 0) dma16_abs(A.bias + 128 + lane * 4, BIAS + 512);   // bias[1] -> slot 1
 #pragma unroll
     for (int j = 0; j < 9; j++) {
@@ -171,8 +200,8 @@ __global__ __launch_bounds__(256, 1) void k_tower1w(TowerArgs A)
         f32x4 b8[8];
 #pragma unroll
         for (int mt = 0; mt < 8; mt++) b8[mt] = *reinterpret_cast<const f32x4 *>(A.bias + chan_row(mt, 4 * q));
-        aset_col<0>(seq8{}, b8); aset_col<1>(seq8{}, b8); aset_col<2>(seq8{}, b8);
-        aset_col<3>(seq8{}, b8); aset_col<4>(seq8{}, b8); aset_col<5>(seq8{}, b8);
+        aset_col<0>(seq8{}, acc, b8); aset_col<1>(seq8{}, acc, b8); aset_col<2>(seq8{}, acc, b8);
+        aset_col<3>(seq8{}, acc, b8); aset_col<4>(seq8{}, acc, b8); aset_col<5>(seq8{}, acc, b8);
     }
     barrier_dma();
     {
@@ -208,8 +237,8 @@ __global__ __launch_bounds__(256, 1) void k_tower1w(TowerArgs A)
             for (int mt = 0; mt < 8; mt++)
                 af[mt] = lds_ld128((tp * COUT + chan_row(mt, r16)) * 32 + (q & 1) * 16);
             __builtin_amdgcn_sched_barrier(0);
-            amfma_col<0>(seq8{}, af, bf[0]); amfma_col<1>(seq8{}, af, bf[1]); amfma_col<2>(seq8{}, af, bf[2]);
-            amfma_col<3>(seq8{}, af, bf[3]); amfma_col<4>(seq8{}, af, bf[4]); amfma_col<5>(seq8{}, af, bf[5]);
+            amfma_col<0>(seq8{}, acc, af, bf[0]); amfma_col<1>(seq8{}, acc, af, bf[1]); amfma_col<2>(seq8{}, acc, af, bf[2]);
+            amfma_col<3>(seq8{}, acc, af, bf[3]); amfma_col<4>(seq8{}, acc, af, bf[4]); amfma_col<5>(seq8{}, acc, af, bf[5]);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -241,28 +270,58 @@ __global__ __launch_bounds__(256, 1) void k_tower1w(TowerArgs A)
     }
     const bool real5 = r16 < PIX - 80, yu0 = r16 >= 9, yd5 = r16 == 0;
     const int Rrow = act_off + r16 * 256, r5 = r16 << 4, q4 = (((q & 1) << 3) | (q >> 1)) << 4;
-    auto tap_addrs = [&](int (&as)[6], int tap) {
+    auto tap_addr = [&](int tap, int nt) -> int {
         const int dy = tap / 3 - 1, dx = tap % 3 - 1, off = dy * 9 + dx;
-        int rrow = Rrow, r5o = r5;
-        asm volatile("" : "+v"(rrow), "+v"(r5o));
-        const int slot = ((r5o + off * 16) & 0x70) ^ q4;
-        const int aok = rrow + off * 256 + slot;
-#pragma unroll
-        for (int nt = 0; nt < 6; nt++) {
-            const bool sel = dx != 0 || (nt == 0 && dy < 0) || nt == 5;
-            if (!sel) { as[nt] = aok; continue; }
-            bool ok = dx < 0 ? xl[nt] : dx > 0 ? xr[nt] : real5;
-            if (dx == 0 && nt == 0) ok = yu0;
-            else if (nt == 0 && dy < 0) ok = ok && yu0;
-            if (nt == 5 && dy > 0) ok = ok && yd5;
-            as[nt] = ok ? aok : slot + (ZROW - nt * 4096);
-        }
+        const int slot = ((r5 + off * 16) & 0x70) ^ q4;
+        const int aok = Rrow + off * 256 + slot;
+        const bool sel = dx != 0 || (nt == 0 && dy < 0) || nt == 5;
+        if (!sel) return aok;
+        bool ok = dx < 0 ? xl[nt] : dx > 0 ? xr[nt] : real5;
+        if (dx == 0 && nt == 0) ok = yu0;
+        else if (nt == 0 && dy < 0) ok = ok && yu0;
+        if (nt == 5 && dy > 0) ok = ok && yd5;
+        return ok ? aok : slot + (ZROW - nt * 4096);
     };
+    // (hipcc hoists the K-step term: all 4 x 54 address variants live in registers - there is room at one wave per SIMD)
     auto load_b1 = [&](bf16x8 &bf, int a, int nt, int ks) { bf = lds_ld128((a ^ (ks << 5)) + nt * 4096); };
+    // The 54 row addresses do not depend on the layer and there are registers to spare at one wave per SIMD: they are
+    // computed once (k_tower16b recomputes a tap's 6 in ~13 VALU instructions, free beside a partner wave; alone on the
+    // SIMD every VALU instruction is 4 cycles of the wave's issue)
+    // (nine arrays of 6, not one of 54: hipcc keeps a 54-entry array in scratch even though every index is a constant
+    // after unrolling)
+    int ta0[6], ta1[6], ta2[6], ta3[6], ta4[6], ta5[6], ta6[6], ta7[6], ta8[6];
+#pragma unroll
+    for (int nt = 0; nt < 6; nt++) {
+        ta0[nt] = tap_addr(0, nt); ta1[nt] = tap_addr(1, nt); ta2[nt] = tap_addr(2, nt);
+        ta3[nt] = tap_addr(3, nt); ta4[nt] = tap_addr(4, nt); ta5[nt] = tap_addr(5, nt);
+        ta6[nt] = tap_addr(6, nt); ta7[nt] = tap_addr(7, nt); ta8[nt] = tap_addr(8, nt);
+    }
+    // (the tap is a template constant in the main loop: a runtime switch here would keep hipcc from unrolling the tap loop)
+    auto tapa = [&](auto tapc, int nt) -> int {
+        constexpr int tap = decltype(tapc)::value;
+        if constexpr (tap == 0) return ta0[nt];
+        else if constexpr (tap == 1) return ta1[nt];
+        else if constexpr (tap == 2) return ta2[nt];
+        else if constexpr (tap == 3) return ta3[nt];
+        else if constexpr (tap == 4) return ta4[nt];
+        else if constexpr (tap == 5) return ta5[nt];
+        else if constexpr (tap == 6) return ta6[nt];
+        else if constexpr (tap == 7) return ta7[nt];
+        else return ta8[nt];
+    };
 
     // epilogue of one layer (wave-local): acc -> bf16 -> ReLU -> LDS rows in place; the next layer's accumulators start
     // at its bias (+ the block input x for the second convolution of a block, read back from the rows being overwritten)
-    auto epilogue = [&](auto read_x, int lb_next) {
+    // fine stamps inside the epilogues of layers 2 (first convolution of a block) and 3: slots 30 + 6 * (layer - 2) + i
+    auto fstamp = [&](int layer, int i) {
+        if constexpr (STAMP) {
+            if (stamping && (layer == 2 || layer == 3)) {
+                const unsigned long long t = __builtin_amdgcn_s_memtime();
+                if (threadIdx.x == 0) A.stamps[(size_t)blockIdx.x * 64 + 30 + 6 * (layer - 2) + i] = t;
+            }
+        }
+    };
+    auto epilogue = [&](auto read_x, int lb_next, int layer) {
         constexpr bool RX = decltype(read_x)::value;
         int ln;
         asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
@@ -284,16 +343,22 @@ __global__ __launch_bounds__(256, 1) void k_tower1w(TowerArgs A)
         }
         const bool tail_ok = r < PIX - 80;
         bf16x8 xf[4][6];
+        fstamp(layer, 0);
         asm volatile("s_nop 15\n\ts_nop 15");                          // the layer's last MFMAs -> v_accvgpr_read (no interlock for asm)
-        epi_pair<0, RX>(seq6{}, sb, tail_ok, lbq, xf[0]);
-        epi_pair<1, RX>(seq6{}, sb, tail_ok, lbq, xf[1]);
-        epi_pair<2, RX>(seq6{}, sb, tail_ok, lbq, xf[2]);
-        epi_pair<3, RX>(seq6{}, sb, tail_ok, lbq, xf[3]);
+        epi_pair<0, RX>(seq6{}, acc, sb, tail_ok, lbq, xf[0]);
+        fstamp(layer, 1);
+        epi_pair<1, RX>(seq6{}, acc, sb, tail_ok, lbq, xf[1]);
+        fstamp(layer, 2);
+        epi_pair<2, RX>(seq6{}, acc, sb, tail_ok, lbq, xf[2]);
+        epi_pair<3, RX>(seq6{}, acc, sb, tail_ok, lbq, xf[3]);
+        fstamp(layer, 3);
         await_lds();                                                   // the bias values are in the accumulators
+        fstamp(layer, 4);
         if constexpr (RX) {
-            epi_skip<0>(seq6{}, sel, xf[0]); epi_skip<1>(seq6{}, sel, xf[1]);
-            epi_skip<2>(seq6{}, sel, xf[2]); epi_skip<3>(seq6{}, sel, xf[3]);
+            epi_skip<0>(seq6{}, acc, sel, xf[0]); epi_skip<1>(seq6{}, acc, sel, xf[1]);
+            epi_skip<2>(seq6{}, acc, sel, xf[2]); epi_skip<3>(seq6{}, acc, sel, xf[3]);
         }
+        fstamp(layer, 5);
     };
     using yes = std::integral_constant<bool, true>;
     using no = std::integral_constant<bool, false>;
@@ -302,7 +367,7 @@ __global__ __launch_bounds__(256, 1) void k_tower1w(TowerArgs A)
 #pragma unroll
         for (int j = 0; j < PPW; j++) { stage_piece(0, j); stage_piece(1, j); stage_piece(2, j); }
     }
-    epilogue(no{}, BIAS + 512);                                     // conv1 output; tower layer 0 starts at bias[1]
+    epilogue(no{}, BIAS + 512, -1);                                 // conv1 output; tower layer 0 starts at bias[1]
     barrier_dma();                                                 // stages 0..2 and bias[1] have landed, for every wave
     stamp(2);
 
@@ -316,62 +381,68 @@ __global__ __launch_bounds__(256, 1) void k_tower1w(TowerArgs A)
             dma16_abs(A.bias + (size_t)(layer + 2) * 128 + lane * 4, BIAS + (layer & 1) * 512);
 #pragma unroll
         for (int mt = 0; mt < 8; mt++) load_a1(fa[0][mt], mt, 0, 0);
-        int as[6];
-        tap_addrs(as, 0);
 #pragma unroll
-        for (int nt = 0; nt < 6; nt++) load_b1(fb[0][nt], as[nt], nt, 0);
-#pragma unroll
-        for (int tap = 0; tap < 9; tap++) {
-            int asn[6];
+        for (int nt = 0; nt < 6; nt++) load_b1(fb[0][nt], tapa(std::integral_constant<int, 0>{}, nt), nt, 0);
+        auto do_tap = [&](auto tapc) {
+            constexpr int tap = decltype(tapc)::value;
 #pragma unroll
             for (int ks = 0; ks < 4; ks++) {                        // 4 K-steps of 32 channels = 2 weight stages
                 const int sl = ks >> 1, kk = ks & 1, cur = ks & 1;
                 const int p = tap * 2 + sl;                           // stage of the layer
                 const bool last = tap == 8 && ks == 3;                // last K-step of the layer: no activation prefetch
-                if (ks == 3 && !last) tap_addrs(asn, tap + 1);
 #pragma unroll
                 for (int n = 0; n < 6; n++) {                        // pixel tile n: 8 MFMAs
-                    // the next K-step's fragments: the activation fragment of this tile, one or two weight fragments
+                    // Issue order, every step pinned (the asm MFMAs are invisible to sched_group_barrier): MFMA, the next
+                    // K-step's activation fragment of this tile, MFMA, a weight fragment, MFMA, a second one (tiles 0, 1 at
+                    // kk == 0, tiles 1..3 at kk == 1), MFMA, the stage's DMA piece (tiles 1..4 at kk == 1), 4 MFMAs: one
+                    // filler per 16-cycle MFMA gap (clustered in front of the tile: +4.5 % cycles in the loop probe)
+                    auto lda = [&](int m) {
+                        if (kk == 0) load_a1(fa[cur ^ 1][m], m, p, 1);            // from this stage
+                        else load_a1(fa[cur ^ 1][m], m, p + 1, 0);                // from the stage the barrier (behind tile 0) published
+                    };
+                    int m0 = -1, m1 = -1;
+                    if (kk == 0) { if (n < 2) { m0 = 2 * n; m1 = 2 * n + 1; } else m0 = n + 2; }
+                    else if (n >= 1) { if (n < 4) { m0 = 2 * n - 2; m1 = 2 * n - 1; } else m0 = n + 2; }
+                    __builtin_amdgcn_sched_barrier(0);
+                    amfma_n<0>(acc, n, fa[cur][0], fb[cur][n]);
+                    __builtin_amdgcn_sched_barrier(0);
                     if (!last) {
-                        if (ks < 3) load_b1(fb[cur ^ 1][n], as[n], n, ks + 1);
-                        else load_b1(fb[cur ^ 1][n], asn[n], n, 0);
-                    }
-                    if (kk == 0) {                                    // from this stage: tiles 0, 1 fetch two each, 2..5 one each
-                        if (n < 2) { load_a1(fa[cur ^ 1][2 * n], 2 * n, p, 1); load_a1(fa[cur ^ 1][2 * n + 1], 2 * n + 1, p, 1); }
-                        else load_a1(fa[cur ^ 1][n + 2], n + 2, p, 1);
-                    } else if (n >= 1) {                              // from the stage the barrier (behind tile 0) published
-                        if (n < 4) { load_a1(fa[cur ^ 1][2 * n - 2], 2 * n - 2, p + 1, 0); load_a1(fa[cur ^ 1][2 * n - 1], 2 * n - 1, p + 1, 0); }
-                        else load_a1(fa[cur ^ 1][n + 2], n + 2, p + 1, 0);
-                        if (n - 1 < PPW) stage_piece(base + p + 3, n - 1);      // the slot stage p - 1 has left, three stages ahead
+                        if (ks < 3) load_b1(fb[cur ^ 1][n], tapa(tapc, n), n, ks + 1);
+                        else load_b1(fb[cur ^ 1][n], tapa(std::integral_constant<int, (tap < 8 ? tap + 1 : 8)>{}, n), n, 0);
                     }
                     __builtin_amdgcn_sched_barrier(0);
-                    switch (n) {
-                    case 0: amfma_col<0>(seq8{}, fa[cur], fb[cur][0]); break;
-                    case 1: amfma_col<1>(seq8{}, fa[cur], fb[cur][1]); break;
-                    case 2: amfma_col<2>(seq8{}, fa[cur], fb[cur][2]); break;
-                    case 3: amfma_col<3>(seq8{}, fa[cur], fb[cur][3]); break;
-                    case 4: amfma_col<4>(seq8{}, fa[cur], fb[cur][4]); break;
-                    default: amfma_col<5>(seq8{}, fa[cur], fb[cur][5]); break;
-                    }
+                    amfma_n<1>(acc, n, fa[cur][1], fb[cur][n]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (m0 >= 0) lda(m0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    amfma_n<2>(acc, n, fa[cur][2], fb[cur][n]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (m1 >= 0) lda(m1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    amfma_n<3>(acc, n, fa[cur][3], fb[cur][n]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (!(ABL & 4) && kk == 1 && n >= 1 && n - 1 < PPW) stage_piece(base + p + 3, n - 1);   // the slot stage p - 1 has left, three stages ahead
+                    __builtin_amdgcn_sched_barrier(0);
+                    amfma_n<4>(acc, n, fa[cur][4], fb[cur][n]); amfma_n<5>(acc, n, fa[cur][5], fb[cur][n]);
+                    amfma_n<6>(acc, n, fa[cur][6], fb[cur][n]); amfma_n<7>(acc, n, fa[cur][7], fb[cur][n]);
                     __builtin_amdgcn_sched_barrier(0);
                     if (kk == 1 && n == 0) {
                         // stage barrier B_p: the pieces of stage p + 1 (issued two barriers ago) have landed - each wave
                         // waits for its own, leaving the 4 of stage p + 2 in flight - and every wave has finished with
                         // stage p - 1, whose slot the pieces issued behind this barrier refill
-                        __builtin_amdgcn_s_waitcnt(XQ_1W_DEBUG_WAIT);           // vmcnt(4)
-                        __builtin_amdgcn_s_barrier();
+                        if (!(ABL & 2)) __builtin_amdgcn_s_waitcnt(XQ_1W_DEBUG_WAIT);           // vmcnt(4)
+                        if (!(ABL & 1)) __builtin_amdgcn_s_barrier();
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
             }
-            if (tap < 8) {
-#pragma unroll
-                for (int nt = 0; nt < 6; nt++) as[nt] = asn[nt];
-            }
-        }
+        };
+        do_tap(std::integral_constant<int, 0>{}); do_tap(std::integral_constant<int, 1>{}); do_tap(std::integral_constant<int, 2>{});
+        do_tap(std::integral_constant<int, 3>{}); do_tap(std::integral_constant<int, 4>{}); do_tap(std::integral_constant<int, 5>{});
+        do_tap(std::integral_constant<int, 6>{}); do_tap(std::integral_constant<int, 7>{}); do_tap(std::integral_constant<int, 8>{});
         if (layer < 28) stamp(3 + 2 * layer);
-        if (layer & 1) epilogue(no{}, BIAS + (layer & 1) * 512);
-        else epilogue(yes{}, BIAS + (layer & 1) * 512);
+        if (layer & 1) epilogue(no{}, BIAS + (layer & 1) * 512, layer);
+        else epilogue(yes{}, BIAS + (layer & 1) * 512, layer);
         if (layer < 28) stamp(4 + 2 * layer);
     }
 
@@ -414,7 +485,6 @@ __global__ __launch_bounds__(256, 1) void k_tower1w(TowerArgs A)
                 hacc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ha[m], hb[nt], hacc[m][nt], 0, 0, 0);
     }
     stamp(60);
-    if (!board_ok) { stamp(61); return; }
     uint8_t *Pb = reinterpret_cast<uint8_t *>(A.P) + (size_t)board * PIX * 64;
     uint8_t *Vb = reinterpret_cast<uint8_t *>(A.V) + (size_t)board * PIX * 16;
 #pragma unroll
@@ -424,7 +494,7 @@ __global__ __launch_bounds__(256, 1) void k_tower1w(TowerArgs A)
 #pragma unroll
         for (int nt = 0; nt < 6; nt++) {
             const int p = nt * 16 + r16;
-            if (p < PIX && (m < 2 || q < 2)) {                       // value head: channels 32..39 only
+            if (board_ok && p < PIX && (m < 2 || q < 2)) {           // value head: channels 32..39 only
                 const float v0 = hacc[m][nt][0] + b4[0], v1 = hacc[m][nt][1] + b4[1];
                 const float v2 = hacc[m][nt][2] + b4[2], v3 = hacc[m][nt][3] + b4[3];
                 const uint2 pk = make_uint2(relu_bf16x2(pack_bf16x2(v0, v1)), relu_bf16x2(pack_bf16x2(v2, v3)));
@@ -434,6 +504,8 @@ __global__ __launch_bounds__(256, 1) void k_tower1w(TowerArgs A)
         }
     }
     stamp(61);
+    stamping = false;
+    }
 }
 
 }  // namespace
@@ -573,7 +645,8 @@ __global__ __launch_bounds__(256, 2) void k_mfma_probe16(const uint32_t *seed, f
 // of 32 channels = 2 weight stages; fragments double-buffered by K-step, 4 LDS-DMA pieces per wave and stage, the
 // kernel's swizzled addresses (conflict-free).
 namespace {
-template <int MT, int WPS, bool AASM = false>
+// OPT (asm builds): 1 = no weight DMA, 2 = one read / DMA piece per MFMA gap instead of a cluster in front of the tile
+template <int MT, int WPS, bool AASM = false, int OPT = 0>
 __global__ __launch_bounds__(256, WPS) void k_loop_probe(const uint32_t *seed, const uint8_t *wsrc, float *out, int taps)
 {
     constexpr int NBP = MT == 4 ? 2 : 4, ACT0 = 2 * WBUF_BYTES;
@@ -597,10 +670,11 @@ __global__ __launch_bounds__(256, WPS) void k_loop_probe(const uint32_t *seed, c
     const rsrc_t wr = make_rsrc(wsrc, 216 * 16384);
     const int voff = (lane >> 3) * 256 + (((lane & 7) ^ (lane >> 4)) << 4);
     f32x4 acc[AASM ? 1 : MT][6];
+    f32x4 accA[AASM ? 48 : 1];
     if constexpr (AASM) {
         XQ_AGPR_ALL();
         const f32x4 z4 = f32x4{ 0.f, 0.f, 0.f, 0.f };
-        aset_all(std::make_integer_sequence<int, MT * 6>{}, z4);
+        aset_all(std::make_integer_sequence<int, MT * 6>{}, accA, z4);
     } else {
 #pragma unroll
         for (int m = 0; m < MT; m++)
@@ -629,6 +703,39 @@ __global__ __launch_bounds__(256, WPS) void k_loop_probe(const uint32_t *seed, c
             const int sl = ks >> 1, kk = ks & 1, cur = ks & 1;
 #pragma unroll
             for (int n = 0; n < 6; n++) {
+                if constexpr (AASM && (OPT & 2) != 0) {
+                    // interleaved issue: MFMA, B read, MFMA, A read, MFMA, A read, MFMA, DMA piece, 4 MFMAs - every step pinned
+                    const int a_nx = ks < 3 ? as : asn;
+                    const int m0 = n < 2 ? 2 * n : n + 2, m1 = n < 2 ? 2 * n + 1 : -1;
+                    auto lda = [&](int m) {
+                        if (kk == 0) fa[cur ^ 1][m] = lds_ld128((abase ^ (1 << 6)) + sl * WBUF_BYTES + m * 2048);
+                        else fa[cur ^ 1][m] = lds_ld128(abase + (sl ^ 1) * WBUF_BYTES + m * 2048);
+                    };
+                    __builtin_amdgcn_sched_barrier(0);
+                    amfma_n<0>(accA, n, fa[cur][0], fb[cur][n]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    fb[cur ^ 1][n] = lds_ld128((a_nx ^ (((ks + 1) & 3) << 5)) + (n < 5 ? n : 4) * 4096);
+                    __builtin_amdgcn_sched_barrier(0);
+                    amfma_n<1>(accA, n, fa[cur][1], fb[cur][n]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    lda(m0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    amfma_n<2>(accA, n, fa[cur][2], fb[cur][n]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (m1 >= 0) lda(m1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    amfma_n<3>(accA, n, fa[cur][3], fb[cur][n]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (!(OPT & 1) && kk == 1 && n >= 1 && n < 5) {
+                        const int g = (t * 2 + sl + 2) % 216;
+                        dma16_buf_abs(wr, voff, g * 16384 + (wave * 4 + n - 1) * 1024, sl * WBUF_BYTES + (wave * 4 + n - 1) * 1024);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    amfma_n<4>(accA, n, fa[cur][4], fb[cur][n]); amfma_n<5>(accA, n, fa[cur][5], fb[cur][n]);
+                    amfma_n<6>(accA, n, fa[cur][6], fb[cur][n]); amfma_n<7>(accA, n, fa[cur][7], fb[cur][n]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    continue;
+                }
                 // next K-step's fragments
                 const int a_next = ks < 3 ? as : asn;
                 fb[cur ^ 1][n] = lds_ld128((a_next ^ (((ks + 1) & 3) << 5)) + (n < 5 ? n : 4) * 4096);
@@ -641,7 +748,7 @@ __global__ __launch_bounds__(256, WPS) void k_loop_probe(const uint32_t *seed, c
                     }
                 }
                 (void)APT;
-                if (kk == 1 && n >= 1 && n < 5) {
+                if (!(OPT & 1) && kk == 1 && n >= 1 && n < 5) {
                     const int g = (t * 2 + sl + 2) % 216;
                     dma16_buf_abs(wr, voff, g * 16384 + (wave * 4 + n - 1) * 1024, sl * WBUF_BYTES + (wave * 4 + n - 1) * 1024);
                 }
@@ -649,12 +756,12 @@ __global__ __launch_bounds__(256, WPS) void k_loop_probe(const uint32_t *seed, c
                     // (asm MFMAs are invisible to sched_group_barrier: a tile's reads / DMA piece are pinned in front of its MFMAs)
                     __builtin_amdgcn_sched_barrier(0);
                     switch (n) {
-                    case 0: amfma_col<0>(std::make_integer_sequence<int, MT>{}, fa[cur], fb[cur][0]); break;
-                    case 1: amfma_col<1>(std::make_integer_sequence<int, MT>{}, fa[cur], fb[cur][1]); break;
-                    case 2: amfma_col<2>(std::make_integer_sequence<int, MT>{}, fa[cur], fb[cur][2]); break;
-                    case 3: amfma_col<3>(std::make_integer_sequence<int, MT>{}, fa[cur], fb[cur][3]); break;
-                    case 4: amfma_col<4>(std::make_integer_sequence<int, MT>{}, fa[cur], fb[cur][4]); break;
-                    default: amfma_col<5>(std::make_integer_sequence<int, MT>{}, fa[cur], fb[cur][5]); break;
+                    case 0: amfma_col<0>(std::make_integer_sequence<int, MT>{}, accA, fa[cur], fb[cur][0]); break;
+                    case 1: amfma_col<1>(std::make_integer_sequence<int, MT>{}, accA, fa[cur], fb[cur][1]); break;
+                    case 2: amfma_col<2>(std::make_integer_sequence<int, MT>{}, accA, fa[cur], fb[cur][2]); break;
+                    case 3: amfma_col<3>(std::make_integer_sequence<int, MT>{}, accA, fa[cur], fb[cur][3]); break;
+                    case 4: amfma_col<4>(std::make_integer_sequence<int, MT>{}, accA, fa[cur], fb[cur][4]); break;
+                    default: amfma_col<5>(std::make_integer_sequence<int, MT>{}, accA, fa[cur], fb[cur][5]); break;
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 } else {
@@ -677,7 +784,7 @@ __global__ __launch_bounds__(256, WPS) void k_loop_probe(const uint32_t *seed, c
     float tsum = 0.f;
     if constexpr (AASM) {
         asm volatile("s_nop 15\n\ts_nop 15");                       // MFMA results -> v_accvgpr_read: no interlock for asm
-        f32x4 t4 = aget<0>() + aget<MT * 6 - 1>();
+        f32x4 t4 = aget<0>(accA[0]) + aget<MT * 6 - 1>(accA[MT * 6 - 1]);
         tsum = t4[0] + t4[1] + t4[2] + t4[3];
     } else {
 #pragma unroll
@@ -698,7 +805,7 @@ extern "C" int xq_mfma_probe(void *stream, const void *seed64_dev, const void *w
                              int iters, int mode)
 {
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (mode >= 20 && mode <= 22) {       // steady-state loop probes: 20 = 64 x 96 wave tile, 2 waves per SIMD; 21 = 128 x 96, one wave per SIMD
+    if (mode >= 20 && mode <= 25) {       // steady-state loop probes: 20 = 64 x 96 wave tile, 2 waves per SIMD; 21 = 128 x 96, one wave per SIMD
         const int lds = mode == 20 ? 2 * WBUF_BYTES + 2 * ACT_BYTES : 2 * WBUF_BYTES + 4 * ACT_BYTES;
         if (mode == 20) {
             if (int rc = tower_lds_opt_in<&k_loop_probe<4, 2>>(lds)) return rc;
@@ -706,9 +813,18 @@ extern "C" int xq_mfma_probe(void *stream, const void *seed64_dev, const void *w
         } else if (mode == 21) {
             if (int rc = tower_lds_opt_in<&k_loop_probe<8, 1>>(lds)) return rc;
             hipLaunchKernelGGL((k_loop_probe<8, 1>), dim3(n_workgroups), dim3(256), lds, st, (const uint32_t *)seed64_dev, (const uint8_t *)weights_dev, (float *)out_dev, iters);
-        } else {                            // 22: the same with the accumulators on literal AGPRs (asm MFMAs)
+        } else if (mode == 22) {            // the same with the accumulators on literal AGPRs (asm MFMAs)
             if (int rc = tower_lds_opt_in<&k_loop_probe<8, 1, true>>(lds)) return rc;
             hipLaunchKernelGGL((k_loop_probe<8, 1, true>), dim3(n_workgroups), dim3(256), lds, st, (const uint32_t *)seed64_dev, (const uint8_t *)weights_dev, (float *)out_dev, iters);
+        } else if (mode == 23) {            // ... without the weight DMA
+            if (int rc = tower_lds_opt_in<&k_loop_probe<8, 1, true, 1>>(lds)) return rc;
+            hipLaunchKernelGGL((k_loop_probe<8, 1, true, 1>), dim3(n_workgroups), dim3(256), lds, st, (const uint32_t *)seed64_dev, (const uint8_t *)weights_dev, (float *)out_dev, iters);
+        } else if (mode == 24) {            // ... one read / DMA piece per MFMA gap
+            if (int rc = tower_lds_opt_in<&k_loop_probe<8, 1, true, 2>>(lds)) return rc;
+            hipLaunchKernelGGL((k_loop_probe<8, 1, true, 2>), dim3(n_workgroups), dim3(256), lds, st, (const uint32_t *)seed64_dev, (const uint8_t *)weights_dev, (float *)out_dev, iters);
+        } else {                            // 25: both
+            if (int rc = tower_lds_opt_in<&k_loop_probe<8, 1, true, 3>>(lds)) return rc;
+            hipLaunchKernelGGL((k_loop_probe<8, 1, true, 3>), dim3(n_workgroups), dim3(256), lds, st, (const uint32_t *)seed64_dev, (const uint8_t *)weights_dev, (float *)out_dev, iters);
         }
         return hipGetLastError() == hipSuccess ? 0 : XQ_E_HIP;
     }

@@ -19,7 +19,9 @@ wts = torch.randint(-2 ** 31, 2 ** 31 - 1, (216 * 16384 // 4,), dtype=torch.int3
 outp = torch.zeros(4, device="cuda")
 taps = 108                       # 12 layers x 9 taps: one workgroup's main-loop work
 for mode, name, nwg, mt in ((20, "64 x 96 tile, 2 waves/SIMD, 2 boards/WG", 8192, 4), (21, "128 x 96 tile, 1 wave/SIMD, 4 boards/WG", 4096, 8),
-                            (22, "128 x 96, 1 wave/SIMD, accumulators on fixed AGPRs", 4096, 8)) * 3:
+                            (22, "128 x 96, 1 wave/SIMD, accumulators on fixed AGPRs", 4096, 8),
+                            (23, "  ... without the weight DMA", 4096, 8), (24, "  ... one read / DMA piece per MFMA gap", 4096, 8),
+                            (25, "  ... per-gap issue, no DMA", 4096, 8)) * 2:
     if probe(st, seed.data_ptr(), wts.data_ptr(), outp.data_ptr(), nwg, taps, mode) != 0:
         print("mode %d: not in this library (XQ_TOWER_PROBES=1 build needed)" % mode)
         continue

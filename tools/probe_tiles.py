@@ -31,6 +31,7 @@ fn.argtypes = [C.c_void_p] * 9 + [C.c_int, C.c_int, C.c_void_p]
 stamps = torch.zeros((G + 1) // 2 * 64, dtype=torch.int64, device="cuda")
 names = {36: "k_tower16b, 2 boards per workgroup", 39: "k_tower16b, 4 boards per workgroup (lock-step)", 0: "k_tower (32x32x16)",
          50: "k_tower1w: one wave per SIMD, 128 x 96 tile, 4 boards/WG",
+         51: "k_tower1w, no stage barriers (probe)", 52: "k_tower1w, no barriers, no vmcnt waits (probe)", 53: "k_tower1w, no barriers / waits / DMA (probe)",
          30: "k_tower16b<2>, no weight refills (probe)", 31: "k_tower16b<2>, no stage barriers (probe)",
          41: "k_tower16b<4>, NO stage barriers (probe)", 43: "k_tower16b<4>, no barriers, no refills (probe)"}
 for variant in [int(v) for v in sys.argv[1:]] or (36, 39, 50, 36, 39, 50):
@@ -59,5 +60,11 @@ for variant in [int(v) for v in sys.argv[1:]] or (36, 39, 50, 36, 39, 50):
         print("    input conv %d + epilogue %d | main loops %s | epilogues %s | heads %d + stores %d" % (
             np.median(s[:, 1] - s[:, 0]), np.median(s[:, 2] - s[:, 1]), main, epi, np.median(s[:, 60] - s[:, 2 + 2 * nl]),
             np.median(s[:, 61] - s[:, 60])))
+    if os.environ.get("XQ_PROBE_PHASES") and variant in (50, 51, 52) and s[:, 30].max() > 0:
+        for layer in (2, 3):
+            f = s[:, 30 + 6 * (layer - 2):30 + 6 * (layer - 2) + 6]
+            d = np.median(np.diff(f, axis=1), axis=0)
+            print("    epilogue of layer %d: pair 0 %d, pair 1 %d, pairs 2 + 3 %d, wait for the bias loads %d, skip MFMAs %d cycles" % (
+                layer, d[0], d[1], d[2], d[3], d[4]))
     stamps.zero_()
 L.xq_tower_set_variant(-1)
