@@ -677,49 +677,57 @@ __global__ __launch_bounds__(64) void k_hashnet(Eng E, int salt)
 constexpr int ROW_HIST = 65536;
 __global__ __launch_bounds__(1024) void k_assign_rows(Eng E, int n_slots, unsigned seq)
 {
-    // 16 chunks of 1,024 slots per pass: every thread first loads its 16 flags (independent loads: one memory latency
-    // for the pass instead of one per chunk), then one wave scans the 16 x 16 per-(chunk, wave) counts
-    constexpr int CH = 16;
-    __shared__ int cnt[CH * 16], off[CH * 16 + 1];
+    // 16 consecutive slots per thread and pass (two 16-byte loads of the u16 leaf_node entries), a shuffle scan inside the
+    // wave, 16 wave totals through LDS: rows come out in slot order.  A slot counts when it holds a pending leaf; a game
+    // that is over has none (its last leaves were consumed by k_end_search before k_play_move ended it).
+    __shared__ int wtot[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int base = 0;
-    for (int start = 0; start < n_slots; start += CH * 1024) {
-        bool pend[CH];
-        unsigned long long mask[CH];
-#pragma unroll
-        for (int c = 0; c < CH; c++) {
-            const int slot = start + c * 1024 + tid;
-            pend[c] = slot < n_slots && E.leaf_node[slot] != LEAF_NONE && !E.gs[slot / E.leaf_slots].done;
+    for (int start = 0; start < n_slots; start += 16 * 1024) {
+        const int s0 = start + tid * 16;
+        uint32_t w[8] = { 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu };
+        if (s0 + 16 <= n_slots) {
+            const uint4 a = *reinterpret_cast<const uint4 *>(E.leaf_node + s0), b = *reinterpret_cast<const uint4 *>(E.leaf_node + s0 + 8);
+            w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
+        } else {
+            for (int i = 0; i < 16; i++)
+                if (s0 + i < n_slots) {
+                    const uint32_t v = E.leaf_node[s0 + i];
+                    w[i >> 1] = (i & 1) ? (w[i >> 1] & 0x0000ffffu) | (v << 16) : (w[i >> 1] & 0xffff0000u) | v;
+                }
         }
+        uint32_t flags = 0;                                  // bit i: slot s0 + i holds a pending leaf
 #pragma unroll
-        for (int c = 0; c < CH; c++) {
-            mask[c] = __ballot(pend[c]);
-            if (lane == 0) cnt[c * 16 + wave] = __popcll(mask[c]);
+        for (int i = 0; i < 16; i++) {
+            const uint32_t v = (i & 1) ? w[i >> 1] >> 16 : w[i >> 1] & 0xffffu;
+            if (v != LEAF_NONE) flags |= 1u << i;
         }
+        const int mine = __popc(flags);
+        int incl = mine;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d, 64); if (lane >= d) incl += o; }
+        if (lane == 63) wtot[wave] = incl;
         __syncthreads();
-        if (wave == 0) {                                  // exclusive scan of the 256 counts in (chunk, wave) order
-            int v[4], sum = 0;
+        int off = base + incl - mine, total = 0;
 #pragma unroll
-            for (int i = 0; i < 4; i++) { v[i] = cnt[lane * 4 + i]; sum += v[i]; }
-            int incl = sum;
+        for (int k = 0; k < 16; k++) { const int c = wtot[k]; off += k < wave ? c : 0; total += c; }
+        int rows[16];
+        int r = off;
 #pragma unroll
-            for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d, 64); if (lane >= d) incl += o; }
-            int run = incl - sum;
-#pragma unroll
-            for (int i = 0; i < 4; i++) { off[lane * 4 + i] = run; run += v[i]; }
-            if (lane == 63) off[CH * 16] = incl;
+        for (int i = 0; i < 16; i++) {
+            const bool p = (flags >> i) & 1u;
+            rows[i] = p ? r : -1;
+            if (p) { E.row_src[r] = s0 + i; r++; }
         }
-        __syncthreads();
+        if (s0 + 16 <= n_slots) {
 #pragma unroll
-        for (int c = 0; c < CH; c++) {
-            const int slot = start + c * 1024 + tid;
-            if (slot < n_slots) {
-                const int row = pend[c] ? base + off[c * 16 + wave] + __popcll(mask[c] & ((1ull << lane) - 1ull)) : -1;
-                E.leaf_row[slot] = row;
-                if (pend[c]) E.row_src[row] = slot;
-            }
+            for (int i = 0; i < 4; i++)
+                reinterpret_cast<int4 *>(E.leaf_row + s0)[i] = make_int4(rows[4 * i], rows[4 * i + 1], rows[4 * i + 2], rows[4 * i + 3]);
+        } else {
+            for (int i = 0; i < 16; i++)
+                if (s0 + i < n_slots) E.leaf_row[s0 + i] = rows[i];
         }
-        base += off[CH * 16];
+        base += total;
         __syncthreads();
     }
     if (tid == 0) { E.row_count[0] = base; E.row_hist[seq & (ROW_HIST - 1)] = base; }
