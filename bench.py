@@ -184,6 +184,9 @@ def main():
                          "per GPU through the --games concurrent slots, a finished game's slot being refilled with the next seed")
     ap.add_argument("--profile-plies", type=int, default=0,
                     help="profiling aid only: stop every step after this many plies (the JSON line is then NOT a benchmark)")
+    ap.add_argument("--no-leaf-dedupe", action="store_true",
+                    help="every pending leaf gets its own network row (default: equal positions of a round share one; "
+                         "value_no_dedupe reports this form beside the headline)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--net-chunk", type=int, default=0, help="rows per network launch (0 = all games at once)")
     ap.add_argument("--root-noise", default="", help="extension (BASELINE C5): 'alpha,eps' Dirichlet root noise, e.g. 0.3,0.25")
@@ -362,10 +365,10 @@ def run_rank(args):
     bcast_bytes = xd.broadcast_weights(net, src=0) if use_dist else 0
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
 
-    def make_ev(policy_columns):
+    def make_ev(policy_columns, leaf_dedupe=True):
         return TorchNetEvaluator(net, dtype=dtype, chunk=args.net_chunk or None, policy_columns=policy_columns,
-                                 fused_tower=bool(args.fused_tower))
-    ev = make_ev(args.policy_columns)
+                                 fused_tower=bool(args.fused_tower), leaf_dedupe=leaf_dedupe)
+    ev = make_ev(args.policy_columns, not args.no_leaf_dedupe)
     stream = torch.cuda.current_stream().cuda_stream
     records = torch.zeros((args.refill if args.refill else G) * _lib.MAX_PLIES * xd.RECORD_BYTES, dtype=torch.uint8, device="cuda")
     pipe = xd.RecordGather(records.numel(), "cuda") if use_dist else None
@@ -479,20 +482,26 @@ def run_rank(args):
                 step(eng, ev_, base + k * TG)
             torch.cuda.synchronize()
             return TG * args.aux_steps / (time.time() - ta)
+        ev_nd = make_ev(args.policy_columns, False) if ev.leaf_dedupe else ev
+        if ev.leaf_dedupe:
+            step(eng, ev_nd, 7_000_000)                                # (untimed: first step after the switch)
+            aux["value_no_dedupe"] = timed_steps(ev_nd, 7_100_000)
         if carry_on:
             eng.set_root_eval_carry(False)
-            step(eng, ev, 8_000_000)                                   # (untimed: first step after the switch)
-            aux["value_no_carry"] = timed_steps(ev, 8_100_000)
+            step(eng, ev_nd, 8_000_000)
+            aux["value_no_carry"] = timed_steps(ev_nd, 8_100_000)
             eng.set_root_eval_carry(None)
         if args.policy_columns == "reachable":
-            ev_all = make_ev("all")
+            ev_all = make_ev("all", ev.leaf_dedupe)
             step(eng, ev_all, 9_000_000)
             aux["value_full_policy_head"] = timed_steps(ev_all, 9_100_000)
             del ev_all
-        aux["aux_note"] = ("games/s over %d extra steps each, same engine, outside the timed region: value_no_carry = every "
-                           "root evaluated afresh (7 forwards per ply, the reference's count; rounds 1 and 2 of this project "
-                           "quoted this form); value_full_policy_head = policy FC on all 8,100 columns (carry-over on)"
-                           % args.aux_steps)
+        del ev_nd
+        aux["aux_note"] = ("games/s over %d extra steps each, same engine, outside the timed region: value_no_dedupe = every "
+                           "pending leaf has its own network row (carry-over on; the round-3a form); value_no_carry = that and "
+                           "every root evaluated afresh, i.e. the reference's evaluation count, 7 forwards of G rows per ply "
+                           "(rounds 1 and 2 of this project quoted this form); value_full_policy_head = policy FC on all 8,100 "
+                           "columns (carry-over and dedupe as in the headline)" % args.aux_steps)
 
     if rank == 0:
         games = TG * world * args.steps
@@ -515,6 +524,8 @@ def run_rank(args):
             # full-size launches: (nearly) every slot has a row - a round in which a few games ended on a terminal leaf or
             # are already over still is one; their flops are counted by the rows they really ran
             full = rows_tw >= 0.98 * rows
+            if not full.any():                             # (a short or small run that the leaf dedupe never lets fill up:
+                full = rows_tw > 0                         #  every launch with rows, priced by the rows it ran)
             n_conv = int(full.sum())
             conv_ms = float(tw_t[full].sum())
             conv_fl = per_board * float(rows_tw[full].mean()) if n_conv else per_board * rows
@@ -546,6 +557,11 @@ def run_rank(args):
                           "figure with every root evaluated afresh)" % (int((rows_fw > 0).sum()), n_fw))
         if eng.row_compaction:
             extras.append("; evaluator row compaction (only slots with a pending leaf are network rows)")
+        if eng.leaf_dedupe:
+            extras.append("; leaf dedupe ON (result-identical, tested at this size: pending leaves of a round that are the same "
+                          "position share one network row - every game starts from the same position with the same weights, so "
+                          "the first plies of a step repeat across games: %d rows evaluated in this run of %d forwards; value_no_dedupe is "
+                          "the figure with one row per pending leaf)" % (int(rows_fw.sum()), n_fw))
         if args.tree_reuse:
             extras.append(", tree reuse (extension)")
         if args.virtual_loss:

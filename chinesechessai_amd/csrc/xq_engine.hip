@@ -99,6 +99,14 @@ struct Eng {
     // row_src[row] = slot (where the search kernel wrote the planes), row_count[0] = rows of this round
     int compact;
     int32_t *leaf_row, *row_src, *row_count, *row_hist;
+    // leaf dedupe (xq_engine_set_leaf_dedupe, needs compaction): slots whose pending leaves are the same position
+    // (board + side to move) share one network row.  dd_tab = open-addressing table of (round tag << 32 | lowest
+    // slot of the position), dd_mask + 1 entries; leaf_pos[slot] = the entry dedupe_insert found for the slot
+    int dedupe, dd_mask;
+    unsigned dd_tag;          // tag of the round being launched (set by the host before every k_search_round)
+    unsigned long long *dd_tab;
+    int32_t *leaf_pos;
+    uint8_t *leaf_dup;        // [slots] 1 = a lower slot holds the same position (cleared by k_assign_rows after reading)
 };
 
 struct __align__(16) WaveLds {
@@ -485,17 +493,87 @@ __global__ __launch_bounds__(64) void k_set_roots(Eng E, const int8_t *boards, c
     }
 }
 
+// Leaf dedupe, first half (called by the wave that has just recorded a pending leaf in `slot`): look the position - the 12
+// packed board dwords + the side to move = everything encode_board reads, neural_network.py:128-146 - up in an
+// open-addressing table shared by all games.  An entry carries the tag of the round that wrote it, so the table is never
+// cleared; the first wave to arrive claims a free entry, later waves with the same position (compared in full, no hash is
+// trusted) lower the entry to the smallest slot of the group with atomicMin and mark the slot that lost - themselves or the
+// previous holder - in leaf_dup: after the kernel exactly the lowest slot of every group is unmarked, whatever the arrival
+// order.  k_assign_rows gives rows to unmarked slots only.  All games of a step start from the same position and share
+// their first plies with many others, so over whole games this removes the network rows of several plies in 70; the
+// results cannot change: the evaluator's output for a position does not depend on the row it sits in.
+__device__ void dedupe_insert(const Eng &E, int slot, uint32_t my_dword /* lane < 12: packed board dword */, int side)
+{
+    const int lane = XQ_LANE;
+    // This leaf's board and side must be visible to every other wave before the table can hand them the slot.  The L2s of
+    // the 8 XCDs are not coherent with each other inside a kernel: an agent-scope release fence would write the whole L2
+    // back (measured: k_search_round 87 -> 320 us); instead the few words other waves read are stored and loaded with
+    // agent-scope atomics (write-through / L2 bypass) and only their completion is waited for here.
+    if (lane < 12) __hip_atomic_store(&E.leaf_board[(size_t)slot * 12 + lane], my_dword, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane == 0) __hip_atomic_store(&E.leaf_side[slot], (int8_t)side, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");             // (compiler ordering; a one-wave workgroup gets no wait from it)
+    __builtin_amdgcn_s_waitcnt(0x0070);                                 // vmcnt(0) lgkmcnt(0): the stores above have landed
+    uint64_t h = 0;
+    if (lane < 12) h = mix64(((uint64_t)(lane + 1) << 32) | my_dword);
+#pragma unroll
+    for (int d = 1; d < 16; d <<= 1) {
+        const uint32_t lo = __shfl_xor((uint32_t)h, d, 64), hi = __shfl_xor((uint32_t)(h >> 32), d, 64);
+        h ^= ((uint64_t)hi << 32) | lo;
+    }
+    const uint32_t hlo = __builtin_amdgcn_readfirstlane((uint32_t)h), hhi = __builtin_amdgcn_readfirstlane((uint32_t)(h >> 32));
+    h = mix64((((uint64_t)hhi << 32) | hlo) ^ (0x9E3779B97F4A7C15ull * (uint64_t)(side + 2)));
+    const unsigned mask = (unsigned)E.dd_mask, tag = E.dd_tag;
+    unsigned pos = (unsigned)h & mask;
+    const unsigned long long mine = ((unsigned long long)tag << 32) | (unsigned)slot;
+    for (unsigned probes = 0; probes <= mask; probes++) {              // (the table holds >= 2 entries per slot: never full)
+        unsigned long long ent = __hip_atomic_load(&E.dd_tab[pos], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((unsigned)(ent >> 32) != tag) {                             // left by an earlier round: free
+            unsigned long long old = 0;
+            if (lane == 0) old = atomicCAS(&E.dd_tab[pos], ent, mine);
+            old = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(old >> 32)) << 32) |
+                  __builtin_amdgcn_readfirstlane((uint32_t)old);
+            if (old == ent) break;                                      // claimed: lowest slot of its position so far
+            ent = old;                                                  // a wave of this round got there first
+        }
+        const unsigned other = (unsigned)ent;
+        uint32_t theirs = 0;
+        if (lane < 12) theirs = __hip_atomic_load(&E.leaf_board[(size_t)other * 12 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int oside = (int8_t)__hip_atomic_load(reinterpret_cast<const uint8_t *>(E.leaf_side) + other, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool same = __ballot(lane < 12 && theirs != my_dword) == 0ull && oside == side;
+        if (same) {
+            if (lane == 0) {
+                // an entry only ever goes down: under a lower slot this one has lost already, no atomic needed (in the
+                // opening all 16,384 games meet in one entry; about ln(16,384) of them ever lower it)
+                unsigned loser = (unsigned)slot;
+                if (other > (unsigned)slot) {
+                    const unsigned long long old = atomicMin(&E.dd_tab[pos], mine);     // same tag on both sides: the lower slot wins
+                    if ((unsigned)old > (unsigned)slot) loser = (unsigned)old;
+                }
+                E.leaf_dup[loser] = 1;
+            }
+            break;
+        }
+        pos = (pos + 1) & mask;
+    }
+    if (lane == 0) E.leaf_pos[slot] = (int32_t)pos;
+}
+
 __device__ void record_leaf(const Eng &E, int slot, WaveLds &L, const int8_t *bd, int side, int node,
                             int depth, int mult, const uint16_t *moves, int n, void *planes, int fmt)
 {
     const int lane = XQ_LANE;
     for (int j = lane; j < n; j += 64) E.leaf_moves[(size_t)slot * MAXM + j] = moves[j];
     if (lane < depth) E.leaf_path[(size_t)slot * PATH_CAP + lane] = L.path_node[lane];
-    if (lane < 12) E.leaf_board[(size_t)slot * 12 + lane] = pack_dword(bd, lane);
+    const uint32_t my_dword = lane < 12 ? pack_dword(bd, lane) : 0u;
+    if (!E.dedupe) {                                          // (with the dedupe: stored by dedupe_insert, past the L2)
+        if (lane < 12) E.leaf_board[(size_t)slot * 12 + lane] = my_dword;
+        if (lane == 0) E.leaf_side[slot] = (int8_t)side;
+    }
     if (lane == 0) {
         E.leaf_node[slot] = (uint16_t)node; E.leaf_mult[slot] = (uint8_t)mult; E.leaf_n[slot] = (uint8_t)n;
-        E.leaf_depth[slot] = (uint8_t)depth; E.leaf_side[slot] = (int8_t)side;
+        E.leaf_depth[slot] = (uint8_t)depth;
     }
+    if (E.dedupe) dedupe_insert(E, slot, my_dword, side);     // (before the planes: its release fence then waits for the few stores above only)
     if (planes) write_planes(bd, side, planes, fmt, slot);
 }
 
@@ -675,6 +753,7 @@ __global__ __launch_bounds__(64) void k_hashnet(Eng E, int salt)
 // prefix inside a wave, 16 partial sums through LDS).  row_src[row] = slot tells the trunk kernel where the search
 // kernel wrote that row's planes; leaf_row[slot] tells consume_eval where the row's logits and value are.
 constexpr int ROW_HIST = 65536;
+
 __global__ __launch_bounds__(1024) void k_assign_rows(Eng E, int n_slots, unsigned seq)
 {
     // 16 consecutive slots per thread and pass (two 16-byte loads of the u16 leaf_node entries), a shuffle scan inside the
@@ -701,6 +780,24 @@ __global__ __launch_bounds__(1024) void k_assign_rows(Eng E, int n_slots, unsign
         for (int i = 0; i < 16; i++) {
             const uint32_t v = (i & 1) ? w[i >> 1] >> 16 : w[i >> 1] & 0xffffu;
             if (v != LEAF_NONE) flags |= 1u << i;
+        }
+        uint32_t dups = 0;                                   // bit i: pending, but a lower slot holds the same position
+        if (E.dedupe) {
+            // the search kernel marked every slot that lost its position to a lower one (dedupe_insert); read the marks and
+            // clear them for the next round
+            if (s0 + 16 <= n_slots) {
+                const uint4 d4 = *reinterpret_cast<const uint4 *>(E.leaf_dup + s0);
+                const uint32_t dw[4] = { d4.x, d4.y, d4.z, d4.w };
+#pragma unroll
+                for (int i = 0; i < 16; i++)
+                    if ((dw[i >> 2] >> ((i & 3) * 8)) & 0xffu) dups |= 1u << i;
+                if (dups) *reinterpret_cast<uint4 *>(E.leaf_dup + s0) = make_uint4(0, 0, 0, 0);
+            } else {
+                for (int i = 0; i < 16; i++)
+                    if (s0 + i < n_slots && E.leaf_dup[s0 + i]) { dups |= 1u << i; E.leaf_dup[s0 + i] = 0; }
+            }
+            dups &= flags;
+            flags &= ~dups;
         }
         const int mine = __popc(flags);
         int incl = mine;
@@ -729,6 +826,17 @@ __global__ __launch_bounds__(1024) void k_assign_rows(Eng E, int n_slots, unsign
         }
         base += total;
         __syncthreads();
+        if (dups) {
+            // the representative = the slot left in the group's table entry = the lowest slot of the group: its row was
+            // written in this pass or an earlier one (before the barrier above; read past the L1 of this CU)
+            const unsigned *tab_lo = reinterpret_cast<const unsigned *>(E.dd_tab);
+#pragma unroll
+            for (int i = 0; i < 16; i++)
+                if ((dups >> i) & 1u) {
+                    const unsigned rep = __hip_atomic_load(&tab_lo[2 * (size_t)(unsigned)E.leaf_pos[s0 + i]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    E.leaf_row[s0 + i] = __hip_atomic_load(&E.leaf_row[rep], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+        }
     }
     if (tid == 0) { E.row_count[0] = base; E.row_hist[seq & (ROW_HIST - 1)] = base; }
 }
@@ -1323,6 +1431,7 @@ struct xq_engine {
     double *uni_all = nullptr; int32_t *slot_game = nullptr, *next_game = nullptr; GameS *out_gs = nullptr;
     int refill_total = 0, refill_cap = 0;     // games of the running session / games the session buffers hold
     unsigned row_seq = 0;                     // search rounds launched with row compaction (index into row_hist)
+    unsigned dd_tag = 0;                      // round tag of the leaf dedupe table (never 0: the cleared table's tag)
     // profiling
     bool prof = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_search, ev_play;
@@ -1339,6 +1448,17 @@ template <class T> static int dalloc(xq_engine *e, T *&p, size_t count)
     e->allocs.push_back(q);
     p = reinterpret_cast<T *>(q);
     return 0;
+}
+
+// leaf dedupe table: at least two entries per pending-leaf slot, a power of two
+static int alloc_dedupe(xq_engine *e, size_t slots)
+{
+    size_t n = 1024;
+    while (n < 2 * slots) n <<= 1;
+    int bad = dalloc(e, e->E.dd_tab, n);
+    bad |= dalloc(e, e->E.leaf_pos, slots); bad |= dalloc(e, e->E.leaf_dup, slots + 16);
+    e->E.dd_mask = (int)(n - 1);
+    return bad;
 }
 
 extern "C" int xq_engine_create(const xq_config *cfg, xq_engine **out)
@@ -1377,7 +1497,7 @@ extern "C" int xq_engine_create(const xq_config *cfg, xq_engine **out)
     bad |= dalloc(e, E.leaf_board, G * 12); bad |= dalloc(e, E.leaf_side, G);
     bad |= dalloc(e, E.priors, G * MAXM); bad |= dalloc(e, E.values, G);
     bad |= dalloc(e, E.leaf_row, G); bad |= dalloc(e, E.row_src, G); bad |= dalloc(e, E.row_count, (size_t)1);
-    bad |= dalloc(e, E.row_hist, (size_t)ROW_HIST);
+    bad |= dalloc(e, E.row_hist, (size_t)ROW_HIST); bad |= alloc_dedupe(e, G);
     bad |= dalloc(e, E.s_board, G * XQ_MAX_PLIES * 12); bad |= dalloc(e, E.s_player, G * XQ_MAX_PLIES);
     bad |= dalloc(e, E.s_n, G * XQ_MAX_PLIES); bad |= dalloc(e, E.s_moves, G * XQ_MAX_PLIES * MAXM);
     bad |= dalloc(e, E.s_counts, G * XQ_MAX_PLIES * MAXM); bad |= dalloc(e, E.s_z, G * XQ_MAX_PLIES);
@@ -1587,7 +1707,7 @@ extern "C" int xq_engine_set_virtual_loss(xq_engine *e, int enable)
         bad |= dalloc(e, E.leaf_depth, S); bad |= dalloc(e, E.leaf_moves, S * MAXM); bad |= dalloc(e, E.leaf_path, S * PATH_CAP);
         bad |= dalloc(e, E.leaf_board, S * 12); bad |= dalloc(e, E.leaf_side, S);
         bad |= dalloc(e, E.priors, S * MAXM); bad |= dalloc(e, E.values, S);
-        bad |= dalloc(e, E.leaf_row, S); bad |= dalloc(e, E.row_src, S);
+        bad |= dalloc(e, E.leaf_row, S); bad |= dalloc(e, E.row_src, S); bad |= alloc_dedupe(e, S);
         if (bad) return fail(XQ_E_HIP, "hipMalloc failed while sizing the pending-leaf slots");
         E.leaf_slots = K;
         HIPCHK(hipMemsetAsync(E.leaf_node, 0xff, S * 2, e->stream));        // LEAF_NONE
@@ -1713,6 +1833,13 @@ extern "C" int xq_engine_search_round(xq_engine *e, int round, int eval_kind, co
         if (ev) HIPCHK(hipEventRecord(ev->first, e->stream));
     }
     const int fmt = planes ? e->cfg.planes_format : XQ_PLANES_NONE;
+    if (e->E.dedupe) {                                                    // a fresh tag for this round's table entries
+        if (++e->dd_tag == 0) {                                           // tag wrap: start from a cleared table
+            HIPCHK(hipMemsetAsync(e->E.dd_tab, 0, ((size_t)e->E.dd_mask + 1) * 8, e->stream));
+            e->dd_tag = 1;
+        }
+        e->E.dd_tag = e->dd_tag;
+    }
 #define XQ_LAUNCH_SEARCH(OCC, VLB) hipLaunchKernelGGL((k_search_round<OCC, VLB>), dim3(e->E.G), dim3(64), 0, e->stream, e->E, \
                                                     round, batch, eval_kind, ev_a, ev_v, planes, fmt)
     if (e->E.vloss) XQ_LAUNCH_SEARCH(4, true);
@@ -1748,6 +1875,22 @@ extern "C" int xq_engine_set_row_compaction(xq_engine *e, int enable)
 {
     if (!e) return fail(XQ_E_INVALID, "null engine");
     e->E.compact = enable ? 1 : 0;
+    if (!enable) e->E.dedupe = 0;
+    return 0;
+}
+
+// Leaf dedupe (default off; needs row compaction): pending leaves that are the same position - same board, same side
+// to move, which is all the network input encodes (neural_network.py:128-146) - share one evaluator row
+// (k_dedupe_leaves + k_assign_rows: leaf_row of every slot of the group = the row of the group's lowest slot).
+// Result-identical for an evaluator whose output for a position depends on nothing else (not on the row, the batch
+// size or the launch: true of xq_tower_nhwc_bf16 / xq_policy_fc_bf16 / xq_value_head_bf16, each output element is one
+// fixed fp32 chain); the caller vouches for that by switching it on.  The reference has no counterpart: its workers
+// evaluate every leaf of every game (self_play.py:137-139).
+extern "C" int xq_engine_set_leaf_dedupe(xq_engine *e, int enable)
+{
+    if (!e) return fail(XQ_E_INVALID, "null engine");
+    if (enable && !e->E.compact) return fail(XQ_E_INVALID, "leaf dedupe needs row compaction (xq_engine_set_row_compaction)");
+    e->E.dedupe = enable ? 1 : 0;
     return 0;
 }
 

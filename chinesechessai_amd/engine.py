@@ -81,10 +81,12 @@ class CallbackEvaluator:
 class TorchNetEvaluator:
     """InferenceNet under PyTorch-ROCm; the search kernel writes its input planes in place.  On the hand-written
     single-launch path the evaluator runs with row compaction: only slots with a pending leaf are network rows
-    (SelfPlayEngine.set_row_compaction)."""
+    (SelfPlayEngine.set_row_compaction), and pending leaves that are the same position share one row
+    (SelfPlayEngine.set_leaf_dedupe; `leaf_dedupe=False` evaluates every pending leaf like the reference does)."""
     deterministic = True
 
-    def __init__(self, net, dtype=None, channels_last=True, chunk=None, policy_columns="reachable", fused_tower=True):
+    def __init__(self, net, dtype=None, channels_last=True, chunk=None, policy_columns="reachable", fused_tower=True,
+                 leaf_dedupe=True):
         import torch
         from .neural_network import InferenceNet
         self.torch = torch
@@ -106,11 +108,16 @@ class TorchNetEvaluator:
         self.chunk = chunk
         self.kind = _lib.EVAL_LOGITS_BF16 if dtype == torch.bfloat16 else _lib.EVAL_LOGITS_F32
         self.row_compaction = bool(self.inet.supports_row_map and not chunk)
+        # the hand-written kernels' output for a position is one fixed fp32 chain per element, whatever the row,
+        # the batch size and the launch: equal positions may share a row
+        self.leaf_dedupe = bool(leaf_dedupe and self.row_compaction)
         self.row_src = self.n_rows_dev = None
 
     def bind(self, engine):
         torch = self.torch
         engine.set_row_compaction(self.row_compaction)
+        if self.row_compaction:
+            engine.set_leaf_dedupe(self.leaf_dedupe)
         self.row_src, self.n_rows_dev = engine.row_map()
         G = engine.n_rows                                       # one row per pending-leaf slot
         if self.channels_last:
@@ -204,6 +211,7 @@ class SelfPlayEngine:
         self.root_eval_carry = None
         self._carry_on = False
         self.row_compaction = False
+        self.leaf_dedupe = False
         self._noise = self._vloss = False
         self.tree_reuse = False
         if stream is not None:
@@ -278,6 +286,15 @@ class SelfPlayEngine:
         kernels take the row map switch it on when they are bound (TorchNetEvaluator on the hand-written path)."""
         _lib.check(self.L.xq_engine_set_row_compaction(self.h, 1 if enable else 0))
         self.row_compaction = bool(enable)
+        if not enable:
+            self.leaf_dedupe = False
+
+    def set_leaf_dedupe(self, enable=True):
+        """Pending leaves of a round that are the same position (board + side to move) share one evaluator row
+        (xq_engine_set_leaf_dedupe; needs row compaction).  Result-identical for an evaluator whose output depends
+        on the position only; the reference evaluates every leaf of every game (self_play.py:137-143)."""
+        _lib.check(self.L.xq_engine_set_leaf_dedupe(self.h, 1 if enable else 0))
+        self.leaf_dedupe = bool(enable)
 
     def row_map(self):
         """(row_src, row_count) device pointers as ints, or (None, None) without compaction."""

@@ -276,6 +276,18 @@ int  xq_engine_row_map(xq_engine *e, const int32_t **row_src_dev, const int32_t 
 int  xq_engine_read_row_history(xq_engine *e, int32_t *rows_host, int cap, int64_t *n_rounds, int reset);
 int  xq_engine_read_leaf_rows(xq_engine *e, int32_t *rows_host /* [G * leaf_slots] */);
 
+/* Leaf dedupe (off until asked for; needs row compaction): pending leaves of one round that are the same position -
+ * same board and same side to move, which is everything encode_board reads (neural_network.py:128-146) - share ONE
+ * evaluator row; every slot of the group reads its logits and value from that row (the row of the group's lowest
+ * slot; positions are compared in full, no hash is trusted).  The reference has no counterpart: each worker
+ * evaluates every leaf of its own game (self_play.py:137-143), although all games of an epoch start from the same
+ * position and, with the same weights, share their first plies with many others.  Result-identical whenever the
+ * evaluator's output for a position depends on nothing but the position (not on the row, the batch or the launch);
+ * the caller vouches for that by switching it on (true of xq_tower_nhwc_bf16 + xq_policy_fc_bf16 +
+ * xq_value_head_bf16).  Row numbering stays deterministic.  Returns XQ_E_INVALID without row compaction;
+ * switching compaction off switches this off. */
+int  xq_engine_set_leaf_dedupe(xq_engine *e, int enable);
+
 /* ---- refill: `total` games through the engine's G concurrent slots, a finished game's slot being restarted
  * on the next unplayed game at once — what the reference's pool does by construction (imap_unordered hands a
  * worker its next game as soon as one ends, self_play.py:404-408).  A game's result depends only on

@@ -450,8 +450,11 @@ def test_planes_and_network_tolerance(L, golden_dir):
                 assert float(ev.x[:, 15].abs().sum()) == 0.0
             kind, a, v = ev.evaluate(eng)
             torch.cuda.synchronize()
-            logits = ev.logits.float().cpu().numpy()
-            values = ev.values.float().cpu().numpy()
+            # a leaf's outputs sit in its evaluator row (row compaction; equal positions of the fixture share one)
+            rows = eng.leaf_rows()
+            assert (rows >= 0).all()
+            logits = ev.logits.float().cpu().numpy()[rows]
+            values = ev.values.float().cpu().numpy()[rows]
             cmap = ev.inet.column_map                       # compact / padded policy rows: move -> column
             host_p = []
             for i in range(n):
@@ -1703,8 +1706,9 @@ def test_root_eval_carry_is_result_identical(L):
     # the bf16 network
     torch.manual_seed(1)
     net = ChessNet(num_blocks=2).eval().cuda()
-    a, ra = play(lambda: TorchNetEvaluator(net), 96, 24, False, max_moves=14)
-    b, rb = play(lambda: TorchNetEvaluator(net), 96, 24, True, max_moves=14)
+    # (leaf_dedupe=False: the row accounting below is the compaction's; tests/test_gpu_round3.py covers the dedupe)
+    a, ra = play(lambda: TorchNetEvaluator(net, leaf_dedupe=False), 96, 24, False, max_moves=14)
+    b, rb = play(lambda: TorchNetEvaluator(net, leaf_dedupe=False), 96, 24, True, max_moves=14)
     assert np.array_equal(a.chosen, b.chosen) and np.array_equal(a.s_counts, b.s_counts)
     assert np.array_equal(a.s_z.view(np.int64), b.s_z.view(np.int64)) and int(b.error.sum()) == 0
     # the hand-written evaluator runs with row compaction: every round is launched, a carried root has no row in round 0

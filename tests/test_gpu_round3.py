@@ -46,7 +46,7 @@ def test_row_compaction_is_result_identical_and_skips_dead_rows(L):
     seeds = np.arange(G, dtype=np.uint32)
 
     def run(compact, carry):
-        ev = TorchNetEvaluator(net)
+        ev = TorchNetEvaluator(net, leaf_dedupe=False)      # (row accounting of the compaction alone; the dedupe has its own test)
         assert ev.row_compaction                    # the hand-written single-launch path asks for it
         ev.row_compaction = compact
         eng = SelfPlayEngine(G, sims=S, planes_format=ev.planes_format, max_moves=P)
@@ -69,7 +69,7 @@ def test_row_compaction_is_result_identical_and_skips_dead_rows(L):
             assert (per[1:, 0] == (0 if carry else G)).all()
 
     # round by round: the carried-over roots of ply 1 have no row in round 0, every slot has one in round 1
-    ev = TorchNetEvaluator(net)
+    ev = TorchNetEvaluator(net, leaf_dedupe=False)
     eng = SelfPlayEngine(G, sims=S, planes_format=ev.planes_format, max_moves=P)
     eng.set_root_eval_carry(True)
     ev.bind(eng)
@@ -111,7 +111,7 @@ def test_c3_full_size_root_eval_carry_is_identical(L):
     seeds = np.arange(G, dtype=np.uint32)
 
     def run(carry):
-        ev = TorchNetEvaluator(net)
+        ev = TorchNetEvaluator(net, leaf_dedupe=False)
         eng = SelfPlayEngine(G, sims=S, planes_format=ev.planes_format, max_moves=P)
         eng.set_root_eval_carry(carry)
         b = eng.play(ev, seeds)
@@ -134,6 +134,124 @@ def test_c3_full_size_root_eval_carry_is_identical(L):
     eng.play(ev, np.arange(64, dtype=np.uint32))
     assert eng._carry_on and eng.row_compaction
     eng.close()
+
+
+def test_leaf_dedupe_is_result_identical_and_groups_exactly(L):
+    """xq_engine_set_leaf_dedupe: pending leaves of a round that are the same position share one network row.  (1) the
+    same games with and without it - bf16 network on the hand-written kernels; moves, visit counts, z bit for bit -
+    with and without the carry-over and with virtual loss; (2) the grouping is exact: two slots share a row if and only
+    if the search kernel wrote the same planes for them, the rows are numbered in the order of each group's lowest
+    slot; (3) at BASELINE C3's size (16,384 games x S = 50 x 6 blocks, 8 plies) the games are unchanged and the opening
+    plies cost almost nothing: every game has the same root and the same first leaves at ply 0 (1 row per round).  The
+    reference evaluates every leaf of every game (self_play.py:137-143)."""
+    import torch
+    from chinesechessai_amd import _lib
+    from chinesechessai_amd.engine import SelfPlayEngine, TorchNetEvaluator
+    from chinesechessai_amd.neural_network import ChessNet
+    torch.manual_seed(3)
+    net = ChessNet(num_blocks=2).eval().cuda()
+    G, S, P = 96, 24, 14
+    seeds = np.arange(G, dtype=np.uint32)
+    keys = ("chosen", "s_counts", "s_moves", "s_n", "winner", "reason", "n_plies", "n_samples", "error")
+
+    def run(net, G, S, P, dedupe, carry=None, vloss=False, seeds=seeds):
+        ev = TorchNetEvaluator(net, leaf_dedupe=dedupe)
+        assert ev.row_compaction and ev.leaf_dedupe == dedupe
+        eng = SelfPlayEngine(G, sims=S, planes_format=ev.planes_format, max_moves=P)
+        if vloss:
+            eng.set_virtual_loss(True)
+        if carry is not None:
+            eng.set_root_eval_carry(carry)
+        b = eng.play(ev, seeds)
+        assert eng.leaf_dedupe == dedupe
+        rows, n = eng.row_history()
+        eng.close()
+        return b, rows
+
+    def same(a, b):
+        for k in keys:
+            assert np.array_equal(getattr(a, k), getattr(b, k)), k
+        assert np.array_equal(a.s_z.view(np.int64), b.s_z.view(np.int64))
+
+    for carry, vloss in ((False, False), (True, False), (None, True)):
+        a, ra = run(net, G, S, P, False, carry, vloss)
+        b, rb = run(net, G, S, P, True, carry, vloss)
+        same(a, b)
+        assert int(a.error.sum()) == 0 and len(ra) == len(rb) and (rb <= ra).all() and rb.sum() < ra.sum()
+        if not vloss:
+            # ply 0: one root position, one tree -> one row per round (none in nobody's round 0 but the first)
+            assert rb[:3].tolist() == [1, 1, 1] and ra[:3].tolist() == [G, G, G]
+            # by the last plies the games have separated: (almost) every slot has its own row again
+            assert rb[-1] > 0.8 * G
+
+    # (2) the grouping, round by round: same planes <=> same row, rows in order of the lowest slot - 8 plies of the small
+    # batch, then 7 plies of 16,384 games (the search kernel's waves of all 256 CUs meet in the table)
+    def grouping(net, G, S, plies):
+        ev = TorchNetEvaluator(net)
+        eng = SelfPlayEngine(G, sims=S, planes_format=ev.planes_format, max_moves=plies + 1)
+        ev.bind(eng)
+        eng.new_games(np.arange(G, dtype=np.uint32))
+        kind, a, v = _lib.EVAL_PRIORS, None, None
+        groups_seen, mixed = [], 0
+        for ply in range(plies):
+            for r in range(eng.rounds):
+                _lib.check(eng.L.xq_engine_search_round(eng.h, r, kind, a, v, ev.planes_ptr()))
+                rows = eng.leaf_rows()
+                planes = ev.storage.reshape(G, -1).view(torch.int16).cpu().numpy()
+                pending = np.nonzero(rows >= 0)[0]
+                first = {}                                              # planes bytes -> lowest slot
+                for sl in pending:
+                    first.setdefault(planes[sl].tobytes(), int(sl))
+                reps = sorted(first.values())
+                row_of = {sl: i for i, sl in enumerate(reps)}
+                want = np.full(G, -1, np.int32)
+                for sl in pending:
+                    want[sl] = row_of[first[planes[sl].tobytes()]]
+                assert np.array_equal(rows, want), (G, ply, r)
+                assert eng.row_history()[0][-1] == len(reps)
+                if len(pending):
+                    groups_seen.append(len(reps))
+                    mixed += 1 if 1 < len(reps) < len(pending) else 0
+                kind, a, v = ev.evaluate(eng)
+            _lib.check(eng.L.xq_engine_end_search(eng.h, kind, a, v))
+            _lib.check(eng.L.xq_engine_play_move(eng.h))
+            kind, a, v = _lib.EVAL_PRIORS, None, None
+        eng.close()
+        return groups_seen, mixed
+
+    groups_seen, mixed = grouping(net, G, S, 8)
+    # (not a test of all-equal or all-distinct positions only: one group at the start, many slots on their own at the end,
+    # rounds with groups of several slots beside single ones in between)
+    assert groups_seen[0] == 1 and groups_seen[-1] > G // 4 and mixed >= 6, (groups_seen, mixed)
+    groups_seen, mixed = grouping(net, 16384, 50, 7)
+    assert groups_seen[0] == 1 and groups_seen[-1] > 4096 and mixed >= 30, (groups_seen[::6], mixed)
+
+    # the option needs the compaction
+    eng = SelfPlayEngine(4, sims=16)
+    with pytest.raises(_lib.XqError):
+        eng.set_leaf_dedupe(True)
+    eng.set_row_compaction(True)
+    eng.set_leaf_dedupe(True)
+    eng.set_row_compaction(False)
+    assert not eng.leaf_dedupe
+    eng.close()
+
+    # (3) BASELINE C3's size
+    torch.manual_seed(0)
+    net6 = ChessNet(num_blocks=6).eval().cuda()
+    G3, P3 = 16384, 8
+    s3 = np.arange(G3, dtype=np.uint32)
+    a, ra = run(net6, G3, 50, P3, False, seeds=s3)
+    b, rb = run(net6, G3, 50, P3, True, seeds=s3)
+    same(a, b)
+    assert int(a.error.sum()) == 0 and (a.n_plies == P3).all()
+    per = rb.reshape(P3, 7)
+    assert per[0].tolist() == [1] * 7 and (per[1:, 0] == 0).all()       # ply 0: one position per round; later roots are carried
+    assert int(ra.sum()) == (6 * P3 + 1) * G3
+    assert (np.diff(per[:, 1:].max(axis=1)) >= 0).all()                 # the games separate ply by ply
+    assert per[1, 1:].max() <= 44 and per[2, 1:].max() <= 44 * 44
+    print("rows per ply with leaf dedupe (C3 size, 8 plies):", per[:, 1:].max(axis=1).tolist(),
+          "total %.3f of the rows without" % (rb.sum() / ra.sum()))
 
 
 def test_c5_single_gpu_workload(L):
