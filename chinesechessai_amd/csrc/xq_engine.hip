@@ -511,8 +511,6 @@ __device__ void dedupe_insert(const Eng &E, int slot, uint32_t my_dword /* lane 
     // agent-scope atomics (write-through / L2 bypass) and only their completion is waited for here.
     if (lane < 12) __hip_atomic_store(&E.leaf_board[(size_t)slot * 12 + lane], my_dword, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (lane == 0) __hip_atomic_store(&E.leaf_side[slot], (int8_t)side, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");             // (compiler ordering; a one-wave workgroup gets no wait from it)
-    __builtin_amdgcn_s_waitcnt(0x0070);                                 // vmcnt(0) lgkmcnt(0): the stores above have landed
     uint64_t h = 0;
     if (lane < 12) h = mix64(((uint64_t)(lane + 1) << 32) | my_dword);
 #pragma unroll
@@ -525,8 +523,13 @@ __device__ void dedupe_insert(const Eng &E, int slot, uint32_t my_dword /* lane 
     const unsigned mask = (unsigned)E.dd_mask, tag = E.dd_tag;
     unsigned pos = (unsigned)h & mask;
     const unsigned long long mine = ((unsigned long long)tag << 32) | (unsigned)slot;
+    // the first look at the table travels together with the stores above; nothing of this wave enters the table before
+    // both have come back (the look is only a hint: the CAS decides)
+    unsigned long long ent = __hip_atomic_load(&E.dd_tab[pos], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");             // (compiler ordering; a one-wave workgroup gets no wait from it)
+    __builtin_amdgcn_s_waitcnt(0x0070);                                 // vmcnt(0) lgkmcnt(0): the stores have landed
     for (unsigned probes = 0; probes <= mask; probes++) {              // (the table holds >= 2 entries per slot: never full)
-        unsigned long long ent = __hip_atomic_load(&E.dd_tab[pos], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (probes) ent = __hip_atomic_load(&E.dd_tab[pos], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if ((unsigned)(ent >> 32) != tag) {                             // left by an earlier round: free
             unsigned long long old = 0;
             if (lane == 0) old = atomicCAS(&E.dd_tab[pos], ent, mine);
@@ -573,8 +576,8 @@ __device__ void record_leaf(const Eng &E, int slot, WaveLds &L, const int8_t *bd
         E.leaf_node[slot] = (uint16_t)node; E.leaf_mult[slot] = (uint8_t)mult; E.leaf_n[slot] = (uint8_t)n;
         E.leaf_depth[slot] = (uint8_t)depth;
     }
-    if (E.dedupe) dedupe_insert(E, slot, my_dword, side);     // (before the planes: its release fence then waits for the few stores above only)
     if (planes) write_planes(bd, side, planes, fmt, slot);
+    if (E.dedupe) dedupe_insert(E, slot, my_dword, side);     // (last: the planes' stores travel while it waits for the table)
 }
 
 // OCC = minimum waves per SIMD requested from the register allocator.  The kernel is a chain of
