@@ -192,6 +192,8 @@ __global__ __launch_bounds__(256) void k_value_head(const uint16_t *__restrict__
     f32x4 acc[8];
 #pragma unroll
     for (int nt = 0; nt < 8; nt++) acc[nt] = *reinterpret_cast<const f32x4 *>(b1 + nt * 16 + 4 * q);
+    // (one K-step at a time on purpose: unrolled - hipcc turns `#pragma unroll 4` into a rolling pipeline of ~10 loads in
+    // flight over all 23 steps - the kernel takes 73 us instead of 20 for 16,384 rows, measured in round 3)
 #pragma unroll 1
     for (int ks = 0; ks < KP / 32; ks++) {
         const bf16x8 x = *reinterpret_cast<const bf16x8 *>(xr + ks * 32);
