@@ -502,7 +502,7 @@ __global__ __launch_bounds__(64) void k_set_roots(Eng E, const int8_t *boards, c
 // order.  k_assign_rows gives rows to unmarked slots only.  All games of a step start from the same position and share
 // their first plies with many others, so over whole games this removes the network rows of several plies in 70; the
 // results cannot change: the evaluator's output for a position does not depend on the row it sits in.
-__device__ void dedupe_insert(const Eng &E, int slot, uint32_t my_dword /* lane < 12: packed board dword */, int side)
+__device__ __forceinline__ void dedupe_insert(const Eng &E, int slot, uint32_t my_dword /* lane < 12: packed board dword */, int side)
 {
     const int lane = XQ_LANE;
     // This leaf's board and side must be visible to every other wave before the table can hand them the slot.  The L2s of
@@ -561,7 +561,7 @@ __device__ void dedupe_insert(const Eng &E, int slot, uint32_t my_dword /* lane 
     if (lane == 0) E.leaf_pos[slot] = (int32_t)pos;
 }
 
-__device__ void record_leaf(const Eng &E, int slot, WaveLds &L, const int8_t *bd, int side, int node,
+__device__ __forceinline__ void record_leaf(const Eng &E, int slot, WaveLds &L, const int8_t *bd, int side, int node,
                             int depth, int mult, const uint16_t *moves, int n, void *planes, int fmt)
 {
     const int lane = XQ_LANE;
