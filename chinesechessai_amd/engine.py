@@ -404,7 +404,15 @@ class SelfPlayEngine:
         carry = self._auto_carry(evaluator, opponent_evaluator)
         evaluator.bind(self)
         if opponent_evaluator is not None:
-            opponent_evaluator.bind(self)
+            # both evaluators work on ONE engine: its row layout (compaction / dedupe) and logit column map are whatever
+            # the evaluator bound last asked for, so the two must ask for the same
+            a, b = evaluator, opponent_evaluator
+            if hasattr(a, "row_compaction") and hasattr(b, "row_compaction") and (
+                    (a.row_compaction, a.leaf_dedupe) != (b.row_compaction, b.leaf_dedupe)
+                    or a.inet.n_policy != b.inet.n_policy):
+                raise _lib.XqError("the two evaluators of a match must use the same row layout and policy columns "
+                                   "(same dtype / layout / chunk / policy_columns / leaf_dedupe)")
+            opponent_evaluator.bind(self)     # (an evaluator that fills priors by slot does not care about the row layout)
         self.new_games(seeds)
         if uniforms is not None:
             self.set_uniforms(uniforms)

@@ -526,3 +526,36 @@ def test_replay_buffer_push_is_exact_and_never_truncates(L):
         buf.push([(np.zeros((10, 9), np.int8), {m: 0.0 for m in too_many}, 0.0)])
     assert len(buf) == cap                                # the refused push changed nothing
     buf.close()
+
+
+def test_match_evaluators_must_share_the_row_layout(L):
+    """Two network evaluators of one match work on one engine (one row layout, one logit column map): a pair that
+    asks for different layouts is refused before a game starts instead of one of them reading the other's rows; a
+    network evaluator beside one that fills priors by slot is fine, and two equal ones play the same match with and
+    without the shared rows."""
+    import torch
+    from chinesechessai_amd import _lib
+    from chinesechessai_amd.engine import HashNetEvaluator, SelfPlayEngine, TorchNetEvaluator
+    from chinesechessai_amd.neural_network import ChessNet
+    torch.manual_seed(5)
+    net_a, net_b = ChessNet(num_blocks=1).eval().cuda(), ChessNet(num_blocks=1).eval().cuda()
+    seeds = np.arange(32, dtype=np.uint32)
+
+    def match(ev_a, ev_b):
+        eng = SelfPlayEngine(32, sims=16, temperature=0.3, max_moves=10, opponent_mode=True, planes_format=ev_a.planes_format)
+        try:
+            return eng.play(ev_a, seeds, opponent_evaluator=ev_b)
+        finally:
+            eng.close()
+
+    for bad in (TorchNetEvaluator(net_b, leaf_dedupe=False), TorchNetEvaluator(net_b, policy_columns="all"),
+                TorchNetEvaluator(net_b, chunk=16)):
+        with pytest.raises(_lib.XqError):
+            match(TorchNetEvaluator(net_a), bad)
+    a = match(TorchNetEvaluator(net_a), TorchNetEvaluator(net_b))
+    b = match(TorchNetEvaluator(net_a, leaf_dedupe=False), TorchNetEvaluator(net_b, leaf_dedupe=False))
+    assert int(a.error.sum()) == 0
+    for k in ("chosen", "s_counts", "winner", "n_plies"):
+        assert np.array_equal(getattr(a, k), getattr(b, k)), k
+    c = match(TorchNetEvaluator(net_a), HashNetEvaluator(1))
+    assert int(c.error.sum()) == 0 and (c.n_plies > 0).all()
