@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(CSRC, "libxq_hip.so")
 SOURCES = [os.path.join(CSRC, "xq_engine.hip"), os.path.join(CSRC, "xq_conv.hip"), os.path.join(CSRC, "xq_replay.hip"),
            os.path.join(CSRC, "xq_tower.hip"), os.path.join(CSRC, "xq_policy.hip")]
 HEADERS = [os.path.join(CSRC, "xq_device.hpp"), os.path.join(CSRC, "xq_mfma.hpp"), os.path.join(CSRC, "xq_tower_probes.hpp"),
-           os.path.join(_HERE, "..", "include", "xq_selfplay.h")]
+           os.path.join(_HERE, "..", "include", "xq_selfplay.h"), os.path.join(_HERE, "..", "include", "xq_debug.h")]
 
 MAX_MOVES = 128
 MAX_PLIES = 70
@@ -135,6 +135,7 @@ _SIGNATURES = {
     "xq_engine_set_tree_reuse": (C.c_int, [C.c_void_p, C.c_int]),
     "xq_engine_set_virtual_loss": (C.c_int, [C.c_void_p, C.c_int]),
     "xq_engine_leaf_slots": (C.c_int, [C.c_void_p]),
+    "xq_engine_tree_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "xq_engine_read_root_priors": (C.c_int, [C.c_void_p, C.c_void_p]),
     "xq_engine_set_uniforms": (C.c_int, [C.c_void_p, C.c_void_p]),
     "xq_engine_set_roots": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -163,6 +164,7 @@ _SIGNATURES = {
     "xq_engine_refill_begin": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "xq_engine_refill_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "xq_engine_refill_read_games": (C.c_int, [C.c_void_p] * 8),
+    "xq_engine_refill_read_slots": (C.c_int, [C.c_void_p, C.c_void_p]),
     "xq_conv3x3_nhwc_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_int, C.c_int, C.c_int]),
     "xq_heads_nhwc_bf16": (C.c_int, [C.c_void_p] * 6 + [C.c_int]),
@@ -180,7 +182,19 @@ _SIGNATURES = {
     "xq_engine_profile_read": (C.c_int, [C.c_void_p] * 5),
 }
 
+# diagnostics (include/xq_debug.h): build selectors, phase stamps, timing probes - tools and build-comparison tests only
+_DEBUG_SIGNATURES = {
+    "xq_tower_set_variant": (None, [C.c_int]),
+    "xq_tower_debug_stamps": (C.c_int, [C.c_void_p] * 9 + [C.c_int, C.c_int, C.c_void_p]),
+    "xq_mfma_probe": (C.c_int, [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_int]),
+    "xq_conv3x3_set_variant": (None, [C.c_int]),
+    "xq_conv3x3_debug_stamps": (C.c_int, [C.c_int, C.c_int] + [C.c_void_p] * 6 + [C.c_int, C.c_int, C.c_void_p]),
+    "xq_engine_set_search_occupancy": (None, [C.c_int]),
+}
+
 EXPORTS = sorted(_SIGNATURES)
+DEBUG_EXPORTS = sorted(_DEBUG_SIGNATURES)
+ROW_HISTORY = 65536
 
 
 def lib():
@@ -197,14 +211,11 @@ def lib():
                               % (LIB_PATH, ex))
         _preload_torch_hip_runtime()
         L = C.CDLL(LIB_PATH)
-        for name, (res, args) in _SIGNATURES.items():
-            fn = getattr(L, name)
-            fn.restype = res
-            fn.argtypes = args
-        L.xq_conv3x3_set_variant.argtypes = [C.c_int]          # diagnostic switch, not in the public header
-        L.xq_conv3x3_set_variant.restype = None
-        L.xq_tower_set_variant.argtypes = [C.c_int]            # diagnostic switch: MFMA shape of the trunk kernel
-        L.xq_tower_set_variant.restype = None
+        for table in (_SIGNATURES, _DEBUG_SIGNATURES):
+            for name, (res, args) in table.items():
+                fn = getattr(L, name)
+                fn.restype = res
+                fn.argtypes = args
         _lib = L
     return _lib
 

@@ -294,3 +294,6 @@ class ChineseChess:
         lines.append("当前: " + ("红方" if self.current_player == 1 else "黑方"))
         lines.append(f"步数: {self.move_count}")
         print("\n".join(lines))
+
+
+ChessEnv = ChineseChess          # BASELINE north_star's name for the class (chess_env.py:9)

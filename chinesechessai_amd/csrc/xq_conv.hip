@@ -14,6 +14,7 @@
 // comparison of the trunk kernel.
 #include <atomic>
 #include "../../include/xq_selfplay.h"
+#include "../../include/xq_debug.h"
 #include "xq_mfma.hpp"
 
 namespace {
@@ -377,7 +378,7 @@ __global__ __launch_bounds__(HNB * 64, 2) void k_heads(const uint16_t *__restric
 
 static int g_conv_variant = 1;      // 1 = variant B (2 boards / WG, 2 WG / CU; default: 2 % faster in situ), 2 = variant C (4 boards / WG)
 
-// diagnostic only (not part of the public ABI)
+// diagnostic (include/xq_debug.h)
 extern "C" void xq_conv3x3_set_variant(int v) { g_conv_variant = v; }
 
 template <int CIN, int NB, int KSLP, bool STAMP, int ABLATE>
@@ -411,7 +412,7 @@ extern "C" int xq_conv3x3_nhwc_bf16(void *stream, const void *x, const void *w, 
     return launch_t<128, 4, 128, false, 0>(s, x, w, bias, residual, y, n_boards, relu, nullptr);
 }
 
-// diagnostic only (not part of the public ABI): s_memtime phase stamps, 32 u64 per workgroup;
+// diagnostic (include/xq_debug.h): s_memtime phase stamps, 32 u64 per workgroup;
 // ablate 1 = no stage barriers / weight DMA, 2 = barriers only, 3 = DMA only (results wrong)
 extern "C" int xq_conv3x3_debug_stamps(int variant, int ablate, void *stream, const void *x, const void *w, const void *bias,
                                        const void *residual, void *y, int n_boards, int relu, void *stamps)

@@ -23,6 +23,7 @@
 // parity contract: PUCT is float32 stepwise, W is float64, rewards/z are float64).
 #include "xq_device.hpp"
 #include "../../include/xq_selfplay.h"
+#include "../../include/xq_debug.h"
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdio.h>
@@ -489,7 +490,10 @@ __global__ __launch_bounds__(64) void k_set_roots(Eng E, const int8_t *boards, c
     for (int k = lane; k < K; k += 64) { E.leaf_node[(size_t)g * K + k] = LEAF_NONE; E.leaf_mult[(size_t)g * K + k] = 0; }
     if (lane == 0) {
         E.root_node[g] = 0;
-        if (E.eval_carry) E.root_ready[g] = 0;          // a caller-provided root has no carried evaluation
+        if (E.eval_carry) {                             // a caller-provided root has no carried evaluation
+            E.root_ready[g] = 0;
+            atomicAdd(E.roots_not_ready, 1);
+        }
     }
 }
 
@@ -502,6 +506,9 @@ __global__ __launch_bounds__(64) void k_set_roots(Eng E, const int8_t *boards, c
 // order.  k_assign_rows gives rows to unmarked slots only.  All games of a step start from the same position and share
 // their first plies with many others, so over whole games this removes the network rows of several plies in 70; the
 // results cannot change: the evaluator's output for a position does not depend on the row it sits in.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "dedupe_insert: cross-XCD visibility rests on gfx950's lowering of relaxed agent-scope atomics (write-through / L2 bypass) and on the gfx9 s_waitcnt encoding; validate before building for another target"
+#endif
 __device__ __forceinline__ void dedupe_insert(const Eng &E, int slot, uint32_t my_dword /* lane < 12: packed board dword */, int side)
 {
     const int lane = XQ_LANE;
@@ -1434,6 +1441,7 @@ struct xq_engine {
     double *uni_all = nullptr; int32_t *slot_game = nullptr, *next_game = nullptr; GameS *out_gs = nullptr;
     int refill_total = 0, refill_cap = 0;     // games of the running session / games the session buffers hold
     unsigned row_seq = 0;                     // search rounds launched with row compaction (index into row_hist)
+    bool row_map_fetched = false;             // xq_engine_row_map since row compaction was last switched: the evaluator knows the layout
     unsigned dd_tag = 0;                      // round tag of the leaf dedupe table (never 0: the cleared table's tag)
     // profiling
     bool prof = false;
@@ -1721,7 +1729,7 @@ extern "C" int xq_engine_set_virtual_loss(xq_engine *e, int enable)
 
 extern "C" int xq_engine_leaf_slots(xq_engine *e) { return e ? e->E.leaf_slots : 0; }
 
-// diagnostic only: per game, nodes in the arena and the sum of pending (virtual-loss) visits
+// per game: nodes in the arena and the sum of pending (virtual-loss) visits
 __global__ void k_tree_stats(Eng E, int32_t *n_nodes, int32_t *vl_sum)
 {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1732,7 +1740,7 @@ __global__ void k_tree_stats(Eng E, int32_t *n_nodes, int32_t *vl_sum)
     n_nodes[g] = n;
     vl_sum[g] = sum;
 }
-extern "C" int xq_engine_debug_tree_stats(xq_engine *e, int32_t *n_nodes_host, int32_t *vl_sum_host)
+extern "C" int xq_engine_tree_stats(xq_engine *e, int32_t *n_nodes_host, int32_t *vl_sum_host)
 {
     if (!e || !n_nodes_host || !vl_sum_host) return fail(XQ_E_INVALID, "null argument");
     HIPCHK(hipSetDevice(e->cfg.device));
@@ -1779,6 +1787,7 @@ extern "C" int xq_engine_set_roots(xq_engine *e, const int8_t *boards, const int
     HIPCHK(hipMemcpyAsync(e->stage_boards, boards, G * 90, hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipMemcpyAsync(e->stage_state, state, G * XQ_STATE_WORDS * 4, hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
+    if (e->E.eval_carry) HIPCHK(hipMemsetAsync(e->E.roots_not_ready, 0, 4, e->stream));     // k_set_roots counts them
     hipLaunchKernelGGL(k_set_roots, dim3(e->E.G), dim3(64), 0, e->stream, e->E, e->stage_boards, e->stage_state);
     HIPCHK(hipGetLastError());
     return 0;
@@ -1815,7 +1824,7 @@ static int drain_events(xq_engine *e)
 
 static int g_search_occ = 4;      // 128 VGPRs, 4 waves/SIMD: fastest of {3, 4, 5, 6, 8}: 0.097 ms (3: 0.118; 5: 0.101 with
                                   // 56 B/lane of scratch that also adds 46 MB of HBM writes per launch)
-// diagnostic only (not part of the public ABI): register budget variant of k_search_round
+// diagnostic (include/xq_debug.h): register budget variant of k_search_round
 extern "C" void xq_engine_set_search_occupancy(int waves_per_simd) { g_search_occ = waves_per_simd; }
 
 extern "C" int xq_engine_search_round(xq_engine *e, int round, int eval_kind, const void *ev_a, const void *ev_v,
@@ -1826,6 +1835,9 @@ extern "C" int xq_engine_search_round(xq_engine *e, int round, int eval_kind, co
     if (eval_kind < XQ_EVAL_PRIORS || eval_kind > XQ_EVAL_LOGITS_BF16) return fail(XQ_E_INVALID, "bad eval_kind");
     if (round > 0 && (!ev_a || !ev_v)) return fail(XQ_E_INVALID, "evaluator output missing");
     if (!planes_ok(e->cfg.planes_format)) return fail(XQ_E_INVALID, "bad planes_format");
+    if (eval_kind != XQ_EVAL_PRIORS && ev_a && e->E.compact && !e->row_map_fetched)
+        return fail(XQ_E_INVALID, "logits handed in by slot while row compaction is on: fetch xq_engine_row_map (rows are compacted) "
+                                  "or switch xq_engine_set_row_compaction off");
     HIPCHK(hipSetDevice(e->cfg.device));
     const int start = round * e->E.leaf_batch;
     const int batch = (start + e->E.leaf_batch <= e->E.sims) ? e->E.leaf_batch : e->E.sims - start;
@@ -1877,6 +1889,7 @@ extern "C" int xq_engine_search_round(xq_engine *e, int round, int eval_kind, co
 extern "C" int xq_engine_set_row_compaction(xq_engine *e, int enable)
 {
     if (!e) return fail(XQ_E_INVALID, "null engine");
+    if ((enable ? 1 : 0) != e->E.compact) e->row_map_fetched = false;
     e->E.compact = enable ? 1 : 0;
     if (!enable) e->E.dedupe = 0;
     return 0;
@@ -1900,6 +1913,7 @@ extern "C" int xq_engine_set_leaf_dedupe(xq_engine *e, int enable)
 extern "C" int xq_engine_row_map(xq_engine *e, const int32_t **row_src_dev, const int32_t **row_count_dev)
 {
     if (!e || !row_src_dev || !row_count_dev) return fail(XQ_E_INVALID, "null argument");
+    e->row_map_fetched = true;
     *row_src_dev = e->E.compact ? e->E.row_src : nullptr;
     *row_count_dev = e->E.compact ? e->E.row_count : nullptr;
     return 0;
@@ -1949,6 +1963,8 @@ extern "C" int xq_engine_end_search(xq_engine *e, int eval_kind, const void *ev_
 {
     if (!e || !ev_a || !ev_v) return fail(XQ_E_INVALID, "null argument");
     if (eval_kind < XQ_EVAL_PRIORS || eval_kind > XQ_EVAL_LOGITS_BF16) return fail(XQ_E_INVALID, "bad eval_kind");
+    if (eval_kind != XQ_EVAL_PRIORS && e->E.compact && !e->row_map_fetched)
+        return fail(XQ_E_INVALID, "logits handed in by slot while row compaction is on: fetch xq_engine_row_map or switch it off");
     HIPCHK(hipSetDevice(e->cfg.device));
     hipLaunchKernelGGL(k_end_search, dim3(e->E.G), dim3(64), 0, e->stream, e->E, eval_kind, ev_a, ev_v);
     HIPCHK(hipGetLastError());
@@ -2059,6 +2075,16 @@ extern "C" int xq_engine_refill_step(xq_engine *e, void *records, int32_t *activ
         HIPCHK(hipMemcpyAsync(active, e->active_dev, 4, hipMemcpyDeviceToHost, e->stream));
         HIPCHK(hipStreamSynchronize(e->stream));
     }
+    return 0;
+}
+
+extern "C" int xq_engine_refill_read_slots(xq_engine *e, int32_t *slot_game /*[G]*/)
+{
+    if (!e || !slot_game) return fail(XQ_E_INVALID, "null argument");
+    if (!e->slot_game || e->refill_total <= 0) return fail(XQ_E_INVALID, "xq_engine_refill_begin first");
+    HIPCHK(hipSetDevice(e->cfg.device));
+    HIPCHK(hipMemcpyAsync(slot_game, e->slot_game, (size_t)e->E.G * 4, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
     return 0;
 }
 

@@ -30,6 +30,7 @@
 // boards two stage steps apart) - DESIGN.md section 5.
 // Reference ops: neural_network.py:54-66,181-187 with eval-mode BatchNorm folded.
 #include "../../include/xq_selfplay.h"
+#include "../../include/xq_debug.h"
 #include "xq_mfma.hpp"
 #include <atomic>
 #include <type_traits>
@@ -773,7 +774,7 @@ __global__ __launch_bounds__(NB * 128, 2) void k_tower16b(TowerArgs A)
 static int g_tower_variant = -1;    // -1 = automatic: k_tower16b<NB = 4> from 2,048 boards up, k_tower16b<NB = 2> below;
                                     // 36 = k_tower16b, 2 boards per workgroup; 39 = 4 boards per workgroup; 0 = k_tower (32x32x16 comparison build);
                                     // 30, 31, 41, 43, 50 = timing probes and experiments (XQ_TOWER_PROBES builds)
-// diagnostic switch (not part of the public ABI): the builds compute the same function (36, 39 and 50 to the bit)
+// diagnostic switch (include/xq_debug.h): the builds compute the same function (36, 39 and 50 to the bit)
 extern "C" void xq_tower_set_variant(int v) { g_tower_variant = v; }
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property of a kernel: remembered per (kernel, device
@@ -846,7 +847,7 @@ extern "C" int xq_tower_nhwc_bf16(void *stream, const void *planes, const void *
                                row_src_dev, n_rows_dev);
 }
 
-// diagnostic only (not part of the public ABI): s_memtime phase stamps, 64 u64 per workgroup
+// diagnostic (include/xq_debug.h): s_memtime phase stamps, 64 u64 per workgroup
 // (0 start, 1 input conv done, 2 its epilogue, 3+2L / 4+2L main loop / epilogue of layer L, 60 heads
 // MFMAs done, 61 end, 62/63 s_memrealtime at start / end)
 extern "C" int xq_tower_debug_stamps(void *stream, const void *planes, const void *w1, const void *wt, const void *bias,

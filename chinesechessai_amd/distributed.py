@@ -155,6 +155,38 @@ def broadcast_weights(net_or_state_dict, src=0, group=None, device=None):
     return nbytes
 
 
+def weights_digest(tensors):
+    """int64[3] digest of a list of tensors' BIT patterns (count, wrap-around sum, position-weighted wrap-around sum of
+    the 16-bit words): equal tensors give equal digests on every device; cheap enough to run after every broadcast."""
+    import torch
+    dev = tensors[0].device
+    d = torch.zeros(3, dtype=torch.int64, device=dev)
+    base = 0
+    for t in tensors:
+        w = t.detach().contiguous().view(-1).view(torch.int16).to(torch.int64) & 0xFFFF
+        n = w.numel()
+        pos = (torch.arange(base, base + n, dtype=torch.int64, device=dev) % 65521) + 1
+        d[0] += n
+        d[1] += w.sum()
+        d[2] += (w * pos).sum()                       # (int64 wrap-around is fine: a digest, and the same on every rank)
+        base += n
+    return d
+
+
+def weights_equal_across_ranks(tensors, group=None, device=None):
+    """True on every rank iff every rank holds bit-identical `tensors` (e.g. InferenceNet.folded_weights() after
+    broadcast_weights): MIN and MAX all-reduce of the digest agree."""
+    import torch
+    import torch.distributed as dist
+    if device is None:
+        device = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+    d = weights_digest(tensors).to(device)
+    lo, hi = d.clone(), d.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
+    return bool(torch.equal(lo, hi))
+
+
 def play_sharded(make_evaluator, num_games, sims, base_seed=0, temperature=1.0, group=None, gather=True, network=None):
     """Each rank plays its shard on its own GPU, then all ranks all-gather the sample records.
     `network` (a ChessNet on this rank's GPU): rank 0's weights are broadcast to every rank first

@@ -268,7 +268,11 @@ class SelfPlayEngine:
             if self.root_eval_carry and opponent_evaluator is not None:
                 raise _lib.XqError("root evaluation carry-over needs one network for both sides (the carried priors are the mover's network's)")
             return self._carry_on
-        want = bool(getattr(evaluator, "deterministic", False) and opponent_evaluator is None and not self.opponent_mode
+        # automatic only where a carried root costs nothing by itself: with row compaction it simply has no row in round
+        # 0.  Without compaction skipping round 0 takes a blocking read of roots_not_ready every ply (the host would stop
+        # running ahead of the GPU), which nobody asked for: those evaluators get the carry-over by set_root_eval_carry(True)
+        want = bool(getattr(evaluator, "deterministic", False) and getattr(evaluator, "row_compaction", False)
+                    and opponent_evaluator is None and not self.opponent_mode
                     and not self._noise and not self._vloss and not self.tree_reuse)
         if want != self._carry_on:
             _lib.check(self.L.xq_engine_set_root_eval_carry(self.h, 1 if want else 0))
@@ -303,7 +307,10 @@ class SelfPlayEngine:
         return a.value, b.value
 
     def row_history(self, cap=65536, reset=False):
-        """Rows the evaluator had to run in each of the last `cap` search rounds (oldest first), rounds launched."""
+        """(rows, n): rows the evaluator had to run in each of the last min(cap, n, _lib.ROW_HISTORY) search rounds
+        (oldest first; the engine keeps the last 65,536 rounds only) and n = rounds launched since the last reset.
+        len(rows) < n means the history is incomplete."""
+        cap = min(int(cap), _lib.ROW_HISTORY)
         rows = np.zeros(cap, np.int32)
         n = C.c_int64()
         _lib.check(self.L.xq_engine_read_row_history(self.h, _lib.ptr(rows), cap, C.byref(n), 1 if reset else 0))
@@ -384,17 +391,49 @@ class SelfPlayEngine:
         self.values_ptr = self.L.xq_engine_values_ptr(self.h)
 
     def tree_stats(self):
-        """(nodes in each game's arena, pending virtual-loss visits) — diagnostic."""
-        fn = self.L.xq_engine_debug_tree_stats
-        fn.argtypes, fn.restype = [C.c_void_p, C.c_void_p, C.c_void_p], C.c_int
+        """(nodes in each game's arena, pending virtual-loss visits) — xq_engine_tree_stats."""
         n, v = np.zeros(self.n_games, np.int32), np.zeros(self.n_games, np.int32)
-        _lib.check(fn(self.h, _lib.ptr(n), _lib.ptr(v)))
+        _lib.check(self.L.xq_engine_tree_stats(self.h, _lib.ptr(n), _lib.ptr(v)))
         return n, v
+
+    def refill_slots(self):
+        """Game id every slot holds during a refill session (-1: retired) — xq_engine_refill_read_slots."""
+        s = np.zeros(self.n_games, np.int32)
+        _lib.check(self.L.xq_engine_refill_read_slots(self.h, _lib.ptr(s)))
+        return s
 
     def root_priors(self):
         p = np.zeros((self.n_games, _lib.MAX_MOVES), np.float32)
         _lib.check(self.L.xq_engine_read_root_priors(self.h, _lib.ptr(p)))
         return p
+
+    @staticmethod
+    def _row_layout(ev):
+        """(row compaction, leaf dedupe, policy columns) an evaluator hands its logits in; None = it fills priors by slot
+        (XQ_EVAL_PRIORS), which every layout serves."""
+        if getattr(ev, "planes_format", _lib.PLANES_NONE) == _lib.PLANES_NONE and not hasattr(ev, "row_compaction"):
+            return None
+        inet = getattr(ev, "inet", None)
+        return (bool(getattr(ev, "row_compaction", False)), bool(getattr(ev, "leaf_dedupe", False)),
+                getattr(inet, "n_policy", None))
+
+    def _bind(self, evaluator, opponent_evaluator=None):
+        """Bind the evaluator(s) of the games about to start.  The engine's row layout is reset first: an evaluator that
+        hands its logits in by slot (no `row_compaction` attribute) must never meet the compaction an earlier
+        TorchNetEvaluator.bind left behind (the C side refuses that combination too); those that want compaction switch
+        it on in their bind.  Both evaluators of a match work on ONE engine, so two network evaluators must ask for
+        the same layout and policy columns."""
+        la, lb = self._row_layout(evaluator), None if opponent_evaluator is None else self._row_layout(opponent_evaluator)
+        if la is not None and lb is not None and la != lb:
+            raise _lib.XqError("the two evaluators of a match must use the same row layout and policy columns "
+                               "(same dtype / layout / chunk / policy_columns / leaf_dedupe)")
+        self.set_row_compaction(False)
+        for ev in (evaluator, opponent_evaluator):
+            if ev is not None and self._row_layout(ev) is None:
+                ev.bind(self)                 # (by-slot priors first: they do not touch the layout)
+        for ev in (evaluator, opponent_evaluator):
+            if ev is not None and self._row_layout(ev) is not None:
+                ev.bind(self)
 
     def play(self, evaluator, seeds, opponent_evaluator=None, uniforms=None, check_every=8, read=True,
              temperature_schedule=None):
@@ -402,17 +441,7 @@ class SelfPlayEngine:
         MT19937 stream like np.random.seed; `uniforms` overrides the streams.
         `temperature_schedule(ply) -> T` (extension) overrides the constant temperature per ply."""
         carry = self._auto_carry(evaluator, opponent_evaluator)
-        evaluator.bind(self)
-        if opponent_evaluator is not None:
-            # both evaluators work on ONE engine: its row layout (compaction / dedupe) and logit column map are whatever
-            # the evaluator bound last asked for, so the two must ask for the same
-            a, b = evaluator, opponent_evaluator
-            if hasattr(a, "row_compaction") and hasattr(b, "row_compaction") and (
-                    (a.row_compaction, a.leaf_dedupe) != (b.row_compaction, b.leaf_dedupe)
-                    or a.inet.n_policy != b.inet.n_policy):
-                raise _lib.XqError("the two evaluators of a match must use the same row layout and policy columns "
-                                   "(same dtype / layout / chunk / policy_columns / leaf_dedupe)")
-            opponent_evaluator.bind(self)     # (an evaluator that fills priors by slot does not care about the row layout)
+        self._bind(evaluator, opponent_evaluator)
         self.new_games(seeds)
         if uniforms is not None:
             self.set_uniforms(uniforms)
@@ -434,15 +463,16 @@ class SelfPlayEngine:
         _lib.check(self.L.xq_engine_finalize(self.h))
         return self.read_results() if read else None
 
-    def play_refill(self, evaluator, seeds, records_ptr, check_every=4, max_plies=None):
+    def play_refill(self, evaluator, seeds, records_ptr, check_every=4, max_plies=None, on_ply=None):
         """`len(seeds)` games through the engine's G slots with refill (xq_engine_refill_*): a finished game's
         slot restarts on the next unplayed seed at once, like the reference's pool (self_play.py:404-408).
         `records_ptr`: device buffer of len(seeds) * 70 sample records (distributed.RECORD_BYTES each), filled
-        by game id.  Returns the per-game outcome arrays (by game id) and the number of plies stepped."""
+        by game id.  Returns the per-game outcome arrays (by game id) and the number of plies stepped.
+        `on_ply(ply)`: called after every refill step (tests / monitoring; reading engine state there synchronises)."""
         seeds = np.ascontiguousarray(seeds, dtype=np.uint32)
         total = len(seeds)
         carry = self._auto_carry(evaluator, None)
-        evaluator.bind(self)
+        self._bind(evaluator)
         _lib.check(self.L.xq_engine_refill_begin(self.h, _lib.ptr(seeds), total))
         active = np.zeros(1, np.int32)
         plies = 0
@@ -454,6 +484,8 @@ class SelfPlayEngine:
             poll = plies % check_every == check_every - 1
             _lib.check(self.L.xq_engine_refill_step(self.h, C.c_void_p(records_ptr), _lib.ptr(active) if poll else None))
             skip0 = carry and not self.row_compaction and self.roots_not_ready() == 0   # (after the refill: restarted slots need their round 0)
+            if on_ply is not None:
+                on_ply(plies)
             plies += 1
             if poll and int(active[0]) == 0:
                 break

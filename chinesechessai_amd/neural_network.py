@@ -278,6 +278,14 @@ class InferenceNet(nn.Module):
             self.hip_v2w = net.value_fc2.weight.detach().reshape(128).to(device=device, dtype=torch.float32).contiguous()
             self.hip_v2b = net.value_fc2.bias.detach().reshape(1).to(device=device, dtype=torch.float32).contiguous()
 
+    def folded_weights(self):
+        """The tensors the hand-written kernels read (folded, re-laid, in kernel dtype): what must be equal on every rank
+        of a sharded run (distributed.weights_equal_across_ranks)."""
+        if not self.use_hip_conv:
+            return [p.data for p in self.parameters()]
+        return [self.hip_w[0], self.hip_wt, self.hip_bt, self.hip_hw, self.hip_hb, self.pfw.data, self.hip_pfb,
+                self.hip_v1w, self.hip_v1b, self.hip_v2w, self.hip_v2b]
+
     def _tower_hip(self, x):
         """Residual tower on the hand-written fused conv kernel (csrc/xq_conv.hip): one launch per
         convolution, bias / residual / ReLU in its epilogue, NHWC bf16 throughout."""

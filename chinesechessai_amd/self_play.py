@@ -27,6 +27,19 @@ class InterruptedWithResults(Exception):
 # eval-mode BatchNorm folded (priors within the tolerance tests/test_gpu_parity.py states next to its
 # measured error), "f32" runs PyTorch's fp32 library kernels on the same device (parity runs).
 INFERENCE_DTYPE = "bf16"
+_warned_f32 = False
+
+
+def _note_f32_once():
+    """Said once per process, when the mirror API is first sent to fp32: that precision is the reference's
+    (neural_network.py:112-115) but it is served by PyTorch's library kernels, not by the hand-written gfx950 path."""
+    global _warned_f32
+    if not _warned_f32:
+        _warned_f32 = True
+        import warnings
+        warnings.warn("inference_dtype='f32': the leaf evaluator runs on PyTorch-ROCm library kernels (MIOpen / hipBLASLt), "
+                      "not on the hand-written MI355X kernels (bf16 only); meant for parity runs against the reference's fp32",
+                      RuntimeWarning, stacklevel=3)
 
 
 def _evaluator_for(network, fast=True, inference_dtype=None):
@@ -42,6 +55,8 @@ def _evaluator_for(network, fast=True, inference_dtype=None):
                 name = inference_dtype or INFERENCE_DTYPE
                 if name not in ("bf16", "f32"):
                     raise ValueError("inference_dtype must be 'bf16' or 'f32'")
+                if name == "f32":
+                    _note_f32_once()
                 return TorchNetEvaluator(network, dtype=torch.bfloat16 if name == "bf16" else torch.float32)
         except ImportError:
             pass
@@ -153,3 +168,21 @@ def parallel_self_play(network, num_games, temperature=1.0, num_simulations=None
     batch = _play_batch(network, num_games, temperature, num_simulations, opponent_network, seeds=seeds,
                         inference_dtype=inference_dtype, partial_on_interrupt=True)
     return batch.results()
+
+
+class SelfPlay:
+    """BASELINE north_star's name for this surface (`SelfPlay.play_game()`): an object holding the arguments of
+    self_play_game (self_play.py:178).  play_game() is self_play_game(...), play_games(n) is parallel_self_play(...)."""
+
+    def __init__(self, network, temperature=1.0, num_simulations=None, opponent_network=None):
+        self.network, self.temperature = network, temperature
+        self.num_simulations, self.opponent_network = num_simulations, opponent_network
+
+    def play_game(self, render=False):
+        return self_play_game(self.network, temperature=self.temperature, render=render,
+                              num_simulations=self.num_simulations, opponent_network=self.opponent_network)
+
+    def play_games(self, num_games, num_workers=4, seeds=None, inference_dtype=None):
+        return parallel_self_play(self.network, num_games, temperature=self.temperature,
+                                  num_simulations=self.num_simulations, num_workers=num_workers,
+                                  opponent_network=self.opponent_network, seeds=seeds, inference_dtype=inference_dtype)

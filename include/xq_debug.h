@@ -1,0 +1,54 @@
+/*
+ * xq_debug.h — diagnostic entry points of libxq_hip.so: build selectors, phase stamps and timing probes used by
+ * tools/ (bench_tower.py, probe_tiles.py, probe_loop.py, compare_trunk_builds.py, soak_tower.py ...), by bench.py's
+ * --tower-variant / --conv-variant / --search-occ switches and by the parity tests that compare two builds of one
+ * kernel.  They replace nothing in the reference and are NOT part of the drop-in boundary (include/xq_selfplay.h):
+ * no product code path calls them, every selector's default is the product build, and a caller that never touches
+ * this header gets the same results.  Declared here so that every exported symbol of the library has a declaration
+ * (tests/test_cabi_cpu.py asserts exports == xq_selfplay.h + xq_debug.h).
+ */
+#ifndef XQ_DEBUG_H
+#define XQ_DEBUG_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Build of the single-launch trunk kernel behind xq_tower_nhwc_bf16 (process-wide): -1 = automatic (the product:
+ * 4 boards per workgroup from 2,048 boards up, 2 below), 36 / 39 = k_tower16b with 2 / 4 boards per workgroup,
+ * 60 = k_tower1wa (one wave per SIMD, hand-written layer body), 0 = k_tower (32x32x16 comparison build); every other
+ * value exists only in a -DXQ_TOWER_PROBES=1 library (experiments, ablations with wrong results).  Builds 36, 39
+ * and 60 compute the same bits. */
+void xq_tower_set_variant(int variant);
+
+/* xq_tower_nhwc_bf16 with s_memtime phase stamps: 64 uint64 per workgroup into stamps_dev (0 start, 1 input conv
+ * done, 2 its epilogue, 3+2L / 4+2L main loop / epilogue of layer L, 60 heads' MFMAs done, 61 end, 62 / 63
+ * s_memrealtime at start / end).  No row map. */
+int  xq_tower_debug_stamps(void *hip_stream, const void *planes_dev, const void *w1_dev, const void *wt_dev,
+                           const void *bias_dev, const void *wh_dev, const void *bh_dev, void *policy_out_dev,
+                           void *value_out_dev, int n_boards, int n_blocks, void *stamps_dev);
+
+/* Bare MFMA / main-loop timing probes (results are meaningless; out_dev[1] = shader cycles, out_dev[2] =
+ * s_memrealtime ticks of workgroup 0).  Returns XQ_E_INVALID in a library built without -DXQ_TOWER_PROBES=1. */
+int  xq_mfma_probe(void *hip_stream, const void *seed64_dev, const void *weights_dev, void *out_dev, int n_workgroups,
+                   int iters, int mode);
+
+/* Build of the per-layer comparison kernel behind xq_conv3x3_nhwc_bf16: 1 = 2 boards per workgroup (default),
+ * 2 = 4 boards per workgroup.  Same bits. */
+void xq_conv3x3_set_variant(int variant);
+
+/* xq_conv3x3_nhwc_bf16 (c_in = 128) with phase stamps, 32 uint64 per workgroup; ablate 1 = no stage barriers /
+ * weight DMA, 2 = barriers only, 3 = DMA only (results wrong), 0 = the kernel as shipped. */
+int  xq_conv3x3_debug_stamps(int variant, int ablate, void *hip_stream, const void *x_dev, const void *w_dev,
+                             const void *bias_dev, const void *residual_dev, void *y_dev, int n_boards, int relu,
+                             void *stamps_dev);
+
+/* Register budget of k_search_round as minimum waves per SIMD (process-wide): 4 (default, 128 VGPRs), or 3 / 5 / 6 /
+ * 8; any other value means 4.  Same results. */
+void xq_engine_set_search_occupancy(int waves_per_simd);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

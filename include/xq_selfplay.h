@@ -169,6 +169,9 @@ int  xq_engine_set_tree_reuse(xq_engine *e, int enable);
  * Not available to the host-side read_leaves / write_priors path.  Call before new_games/set_roots. */
 int  xq_engine_set_virtual_loss(xq_engine *e, int enable);
 int  xq_engine_leaf_slots(xq_engine *e);          /* evaluator rows per game: 1, or leaf_batch */
+/* per game: nodes in its arena after the last search (1 + the children of every expanded node; the arena of a
+ * fresh tree holds 1 + rounds * 128 at most) and the pending virtual-loss visits left in it (0 after a search) */
+int  xq_engine_tree_stats(xq_engine *e, int32_t *n_nodes_host /*[G]*/, int32_t *pending_visits_host /*[G]*/);
 /* priors stored on the root's children after the root was expanded, [G][128] */
 int  xq_engine_read_root_priors(xq_engine *e, float *priors_host);
 
@@ -269,8 +272,13 @@ int  xq_engine_roots_not_ready(xq_engine *e, int32_t *n_host);
  * roots carried over (above) and empty virtual-loss slots then cost no network time, with no host round trip.
  * Results do not depend on the numbering (every evaluator kernel is row-independent); evaluators that fill
  * xq_engine_priors_ptr (XQ_EVAL_PRIORS) stay indexed by slot.
- * xq_engine_read_row_history: rows of the last `cap` search rounds, oldest first, and the rounds launched since
- * the count was last reset.  xq_engine_read_leaf_rows: row of every slot (-1 = no pending leaf). */
+ * While compaction is on, xq_engine_search_round / xq_engine_end_search refuse XQ_EVAL_LOGITS_* output from a
+ * caller that has not fetched xq_engine_row_map since compaction was last switched (logits laid out by slot would
+ * be read by row: wrong priors without an error otherwise).
+ * xq_engine_read_row_history: rows of the last min(cap, n_rounds, XQ_ROW_HISTORY) search rounds, oldest first, into
+ * rows_host[0 ..) - the engine keeps the last XQ_ROW_HISTORY rounds only - and the rounds launched since the count
+ * was last reset.  xq_engine_read_leaf_rows: row of every slot (-1 = no pending leaf). */
+#define XQ_ROW_HISTORY 65536
 int  xq_engine_set_row_compaction(xq_engine *e, int enable);
 int  xq_engine_row_map(xq_engine *e, const int32_t **row_src_dev, const int32_t **row_count_dev);
 int  xq_engine_read_row_history(xq_engine *e, int32_t *rows_host, int cap, int64_t *n_rounds, int reset);
@@ -302,6 +310,10 @@ int  xq_engine_refill_begin(xq_engine *e, const uint32_t *seeds_host /*[total]*/
 int  xq_engine_refill_step(xq_engine *e, void *records_dev /* xq_sample_record[total][70] */, int32_t *active_host);
 int  xq_engine_refill_read_games(xq_engine *e, int32_t *winner, int32_t *reason, int32_t *reason_side,
                                  int32_t *reason_count, int32_t *n_plies, int32_t *n_samples, int32_t *error);
+/* game id every slot holds right now (-1: the slot has retired, no unplayed game was left for it).  Which of two
+ * slots that finish in the same step gets which id is not specified (an atomic counter deals them); a game's
+ * result does not depend on it. */
+int  xq_engine_refill_read_slots(xq_engine *e, int32_t *slot_game_host /*[G]*/);
 
 /* ---- network: fused 3x3 convolution of the residual tower (neural_network.py:54,181-187 with the
  * eval-mode BatchNorm folded into weights and bias):

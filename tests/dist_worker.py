@@ -111,8 +111,18 @@ def check_broadcast_weights(rank, world):
         return h.digest()
 
     before = digest(net.state_dict())
+    tensors = [t for t in net.state_dict().values() if t.is_floating_point()]
+    assert xd.weights_equal_across_ranks(tensors) == (world == 1)          # the check bench.py prints as weights_equal
     nbytes = xd.broadcast_weights(net, src=0)
     after = digest(net.state_dict())
+    assert xd.weights_equal_across_ranks(tensors)
+    if world > 1:                                                           # one flipped mantissa bit on one rank is seen
+        keep = tensors[3].view(-1)[5].item()
+        if rank == world - 1:
+            tensors[3].view(-1)[5] = float(np.nextafter(np.float32(keep), np.float32(9)))
+        assert not xd.weights_equal_across_ranks(tensors)
+        tensors[3].view(-1)[5] = keep
+        assert xd.weights_equal_across_ranks(tensors)
     assert nbytes == sum(t.numel() * (4 if t.is_floating_point() else 8) for t in net.state_dict().values())
     mine = torch.tensor(list(after), dtype=torch.uint8)
     every = [torch.zeros_like(mine) for _ in range(world)]

@@ -1,0 +1,269 @@
+"""Round-4 GPU tests (`-m gpu`, through the C ABI): refill with the real network (row compaction + leaf dedupe + root
+evaluation carry-over on slots that restart mid-session), BASELINE C5 at its full per-GPU size, and the ADVICE r03
+items (set_roots vs roots_not_ready, logits by slot under row compaction, row history clamp)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def L():
+    from chinesechessai_amd import _lib
+    lib = _lib.lib()
+    assert lib.xq_device_count() > 0, "no GPU visible"
+    assert lib.xq_device_ok(0) == 1, "not a gfx950 device"
+    return lib
+
+
+def _mate_line_net(blocks, seed):
+    """A random-init ChessNet whose policy head is biased toward the reference's own 7-ply mate (tests/golden/known.json
+    `mate_line`, recorded from chess_env.py): policy_fc.bias[from*90+to] += b (neural_network.py:160 indexes logits by
+    move).  Several line moves are legal before their turn (and red's first move is, as a code, also a later black
+    cannon move), so the biases are ordered to keep the line's order; a few waiting moves get a small bias.  The
+    reference's PUCT adds child.value() as seen by the CHILD's side (self_play.py:52), so the search shies away from
+    the mating move itself: it keeps about 9 of 42 visits, and a game that has followed the line ends at ply 7 with
+    probability ~0.2 (measured with the CPU oracle on these weights: 10 of 48 games end at ply 7, the others run to
+    the 70-ply cap).  Random-init games ALL run to the cap and restart in step, which tests nothing about refill."""
+    import torch
+    from chinesechessai_amd.neural_network import ChessNet
+    torch.manual_seed(seed)
+    net = ChessNet(num_blocks=blocks).eval().cuda()
+    line = json.load(open(os.path.join(GOLDEN, "known.json")))["mate_line"]
+    assert line == [6367, 108, 6061, 2320, 5806, 1735, 4189]
+    moves = line + [7362, 6561, 6100, 1621]
+    bias = [14., 14., 14., 10., 10., 17., 13.] + [5., 5., 5., 5.]
+    with torch.no_grad():
+        net.policy_fc.bias[torch.tensor(moves, device="cuda")] += torch.tensor(bias, device="cuda")
+    return net
+
+
+def _same_game(a, b, ctx):
+    """two xq_sample_record[70] rows: every field a consumer reads (moves / counts up to n_moves)"""
+    assert np.array_equal(a["valid"], b["valid"]), ctx
+    for i in np.nonzero(a["valid"])[0]:
+        n = int(a[i]["n_moves"])
+        assert n == int(b[i]["n_moves"]) and int(a[i]["chosen"]) == int(b[i]["chosen"]), (ctx, i)
+        assert int(a[i]["player"]) == int(b[i]["player"]) and np.array_equal(a[i]["board"], b[i]["board"]), (ctx, i)
+        assert a[i]["moves"][:n].tolist() == b[i]["moves"][:n].tolist(), (ctx, i)
+        assert a[i]["counts"][:n].tolist() == b[i]["counts"][:n].tolist(), (ctx, i)
+        assert a[i]["z"].tobytes() == b[i]["z"].tobytes(), (ctx, i)
+
+
+def test_refill_with_the_real_network_equals_lock_step_play(L):
+    """VERDICT r03 missing #2 / weak #2: play_refill with TorchNetEvaluator = row compaction + leaf dedupe + root
+    evaluation carry-over, all automatic, on slots that restart while their neighbours are mid-game - what
+    imap_unordered handing a worker its next game must not change (self_play.py:404-408).  48 games through 16 slots
+    with a network a fifth of whose games end at ply 7 (`_mate_line_net`), so that slots restart at plies 7, 14, 70,
+    77 ... while their neighbours are mid-game.  Every game's records must equal, field for
+    field and z bit for bit, the records of the PLAIN lock-step path for the same seed (all 48 games side by side,
+    every root evaluated afresh, one row per pending leaf); the guard blocks around the record buffer stay
+    untouched; and with the dedupe off the row history shows that round 0 of a ply has exactly one row per slot
+    that was restarted in the step before (a carried-over root has none, nobody else gets one)."""
+    import torch
+    from chinesechessai_amd import _lib, distributed as xd
+    from chinesechessai_amd.engine import SelfPlayEngine, TorchNetEvaluator
+    G, T, S = 16, 48, 50
+    net = _mate_line_net(2, 11)
+    seeds = (np.arange(T, dtype=np.uint32) * 7 + 3).astype(np.uint32)
+
+    # the plain path: lock-step, no carry-over, no dedupe
+    ev = TorchNetEvaluator(net, leaf_dedupe=False)
+    eng = SelfPlayEngine(T, sims=S, planes_format=ev.planes_format)
+    eng.set_root_eval_carry(False)
+    eng.play(ev, seeds, read=False)
+    ref_t = torch.zeros(T * 70 * xd.RECORD_BYTES, dtype=torch.uint8, device="cuda")
+    eng.pack_samples(ref_t.data_ptr())
+    ref_out = eng.read_game_outcomes()
+    eng.close()
+    ref = xd.records_to_numpy(ref_t).reshape(T, 70)
+    lengths = ref_out["n_plies"]
+    assert int(ref_out["error"].sum()) == 0
+    # the crafted network does what it is for: games of several lengths, some of them short
+    assert 4 <= (lengths < 70).sum() <= 40, sorted(lengths.tolist())
+
+    block = 70 * xd.RECORD_BYTES
+    for dedupe in (True, False):
+        ev = TorchNetEvaluator(net, leaf_dedupe=dedupe)
+        eng = SelfPlayEngine(G, sims=S, planes_format=ev.planes_format)
+        buf = torch.full(((T + 2) * block,), 0xA5, dtype=torch.uint8, device="cuda")
+        seen = []
+
+        def on_ply(ply, eng=eng, seen=seen):
+            seen.append((eng.refill_slots(), eng.roots_not_ready()))
+        out, plies = eng.play_refill(ev, seeds, buf.data_ptr() + block, check_every=1, on_ply=on_ply)
+        assert eng._carry_on and eng.row_compaction and eng.leaf_dedupe == dedupe          # everything automatic
+        rows, n_rounds = eng.row_history()
+        eng.close()
+        host = buf.cpu().numpy()
+        assert (host[:block] == 0xA5).all() and (host[-block:] == 0xA5).all()              # guard blocks
+        rec = np.frombuffer(host[block:-block].tobytes(), dtype=xd.RECORD_DTYPE).reshape(T, 70)
+        for k in ("winner", "reason", "reason_side", "reason_count", "n_plies", "n_samples", "error"):
+            assert np.array_equal(out[k], ref_out[k]), (k, dedupe)
+        for g in range(T):
+            _same_game(rec[g], ref[g], (g, dedupe))
+        # fewer plies than three lock-step batches, and slots really restarted out of step
+        assert plies < 3 * 70 and len(seen) == plies
+        R = eng.rounds
+        assert n_rounds == plies * R and len(rows) == n_rounds
+        per = rows.reshape(plies, R)
+        prev = np.arange(G)
+        restarts_at = []
+        for p, (slots, not_ready) in enumerate(seen):
+            restarted = int(((slots != prev) & (slots >= 0)).sum())
+            assert not_ready == restarted, (p, not_ready, restarted)                       # only fresh games need a round 0
+            if restarted:
+                restarts_at.append(p)
+            if p + 1 < plies:
+                if dedupe:      # restarted slots all stand on the start position: they share one row
+                    assert per[p + 1, 0] == (1 if restarted else 0), (p, per[p + 1, 0], restarted)
+                else:
+                    assert per[p + 1, 0] == restarted, (p, per[p + 1, 0], restarted)
+            prev = slots
+        assert per[0, 0] == (1 if dedupe else G)
+        assert len(restarts_at) >= 3 and any(p % 70 != 69 for p in restarts_at), restarts_at
+        if not dedupe:          # rounds 1.. : every slot that is playing and did not end on a terminal leaf has a row
+            assert per[:, 1:].max() <= G and per[1, 1] == G
+
+
+def test_c5_at_its_full_per_gpu_size(L):
+    """VERDICT r03 missing #3: BASELINE configs[4] at the size it names per GPU - 16,384 games x S = 200 x 20-block
+    bf16 x Dirichlet(0.3, 0.25) root noise x temperature cut-off - for 3 plies (cut-off at ply 2).  Every ply's root
+    visits sum to 192, the arena stays below its 3,201 nodes, an oracle replay of 64 games agrees on every legal-move
+    list, the ply after the cut-off plays the first maximum, the noise differs between games, and the whole run is
+    bit-reproducible.  (Nothing to cite in the reference: self_play.py:98-148 has neither noise nor a schedule.)"""
+    import torch
+    from chinesechessai_amd.engine import SelfPlayEngine, TorchNetEvaluator
+    from chinesechessai_amd.neural_network import ChessNet
+    from tests.test_gpu_round3 import _oracle_replay
+    torch.manual_seed(0)
+    net = ChessNet(num_blocks=20).eval().cuda()
+    G, S, P, cut = 16384, 200, 3, 2
+    seeds = np.arange(G, dtype=np.uint32)
+    sched = lambda ply: 1.0 if ply < cut else 0.001
+
+    def run():
+        ev = TorchNetEvaluator(net)
+        eng = SelfPlayEngine(G, sims=S, planes_format=ev.planes_format, max_moves=P)
+        eng.set_root_noise(0.3, 0.25, seed=777)
+        b = eng.play(ev, seeds, temperature_schedule=sched)
+        assert not eng._carry_on and eng.leaf_dedupe          # noise: every root evaluated afresh; equal leaves still share rows
+        nodes, vl = eng.tree_stats()
+        eng.close()
+        return b, nodes, vl
+
+    a, nodes, vl = run()
+    assert int(a.error.sum()) == 0 and (a.n_plies == P).all() and (a.n_samples == P).all()
+    counts = a.s_counts[:, :P].astype(np.int64)
+    assert (counts.sum(axis=2) == S - 8).all()
+    assert nodes.max() < 1 + 25 * 128 and nodes.min() > 25 and int(vl.sum()) == 0
+    am = np.argmax(counts[:, cut], axis=1)
+    assert (a.chosen[:, cut] == a.s_moves[np.arange(G), cut, am]).all()
+    _oracle_replay(a, np.linspace(0, G - 1, 64).astype(int), P)
+    assert len({counts[g, 0].tobytes() for g in range(0, G, 16)}) > G // 16 // 8
+    b, nodes_b, _ = run()
+    assert np.array_equal(a.chosen, b.chosen) and np.array_equal(a.s_counts, b.s_counts)
+    assert np.array_equal(a.s_z.view(np.int64), b.s_z.view(np.int64)) and np.array_equal(nodes, nodes_b)
+
+
+def test_set_roots_after_a_carried_ply_counts_every_root(L):
+    """xq_engine_set_roots clears root_ready under the carry-over, so it must also make
+    xq_engine_roots_not_ready report every game (a caller that skips round 0 at 0 would search unexpanded roots)."""
+    from chinesechessai_amd import _lib
+    from chinesechessai_amd.chess_env import ChineseChess
+    from chinesechessai_amd.engine import HashNetEvaluator, SelfPlayEngine
+    G = 6
+    eng = SelfPlayEngine(G, sims=24)
+    eng.set_root_eval_carry(True)
+    ev = HashNetEvaluator()
+    ev.bind(eng)
+    eng.new_games(np.arange(G, dtype=np.uint32))
+    assert eng.roots_not_ready() == G
+    eng.search(ev)
+    _lib.check(eng.L.xq_engine_play_move(eng.h))
+    assert eng.roots_not_ready() == 0                       # every root carried over
+    env = ChineseChess()
+    st = np.zeros((G, _lib.STATE_WORDS), np.int32)
+    st[:, _lib.S_PLAYER] = 1
+    st[:, _lib.S_WINNER] = _lib.WINNER_NONE
+    st[:, _lib.S_RED_KING] = 9 * 9 + 4
+    st[:, _lib.S_BLACK_KING] = 4
+    eng.set_roots(np.tile(np.ascontiguousarray(env.board, dtype=np.int8).reshape(1, 90), (G, 1)), st)
+    assert eng.roots_not_ready() == G
+    eng.search(ev)                                           # and the search from those roots is a full one
+    moves, visits, n = eng.root_visits()
+    assert (n == 44).all() and (visits.sum(axis=1) == 24 - 8).all()
+    eng.close()
+
+
+def test_logits_by_slot_are_refused_under_row_compaction(L):
+    """an evaluator that hands logits in by slot must not meet the row compaction an earlier
+    TorchNetEvaluator.bind left on the engine: play() resets the layout before binding, and the C side refuses
+    XQ_EVAL_LOGITS_* from a caller that never fetched the row map."""
+    import torch
+    from chinesechessai_amd import _lib
+    from chinesechessai_amd.engine import SelfPlayEngine, TorchNetEvaluator
+    from chinesechessai_amd.neural_network import ChessNet
+    torch.manual_seed(5)
+    net = ChessNet(num_blocks=1).eval().cuda()
+    G = 8
+    seeds = np.arange(G, dtype=np.uint32)
+
+    class BySlot:
+        """a network evaluator that knows nothing about row maps: logits row = slot"""
+        deterministic = True
+
+        def __init__(self, net):
+            self.inner = TorchNetEvaluator(net, chunk=G)     # chunked = the by-slot path of the same kernels
+            self.planes_format = self.inner.planes_format
+            assert not self.inner.row_compaction
+
+        def bind(self, engine):
+            self.inner.bind(engine)
+
+        def planes_ptr(self):
+            return self.inner.planes_ptr()
+
+        def evaluate(self, engine):
+            return self.inner.evaluate(engine)
+
+    ev = TorchNetEvaluator(net)
+    eng = SelfPlayEngine(G, sims=16, planes_format=ev.planes_format, max_moves=3)
+    a = eng.play(ev, seeds)
+    assert eng.row_compaction
+    b = eng.play(BySlot(net), seeds)                         # same engine: the layout is reset, the games are the same
+    assert not eng.row_compaction
+    assert np.array_equal(a.chosen, b.chosen) and np.array_equal(a.s_counts, b.s_counts)
+    # the C side on its own: compaction switched on behind the evaluator's back
+    by_slot = BySlot(net)
+    by_slot.bind(eng)
+    eng.new_games(seeds)
+    eng.set_row_compaction(True)
+    _lib.check(eng.L.xq_engine_search_round(eng.h, 0, _lib.EVAL_PRIORS, None, None, by_slot.planes_ptr()))
+    kind, p, v = by_slot.evaluate(eng)
+    rc = eng.L.xq_engine_search_round(eng.h, 1, kind, p, v, by_slot.planes_ptr())
+    assert rc == -1 and b"row compaction" in eng.L.xq_last_error()
+    assert eng.L.xq_engine_end_search(eng.h, kind, p, v) == -1
+    eng.close()
+
+
+def test_row_history_is_clamped_to_what_the_engine_keeps(L):
+    """row_history(cap > 65,536) must not return unfilled zeros behind the engine's ring."""
+    import torch
+    from chinesechessai_amd import _lib
+    from chinesechessai_amd.engine import SelfPlayEngine, TorchNetEvaluator
+    from chinesechessai_amd.neural_network import ChessNet
+    torch.manual_seed(5)
+    net = ChessNet(num_blocks=1).eval().cuda()
+    ev = TorchNetEvaluator(net)
+    eng = SelfPlayEngine(4, sims=16, planes_format=ev.planes_format, max_moves=2)
+    eng.play(ev, np.arange(4, dtype=np.uint32))
+    rows, n = eng.row_history(cap=1 << 20)
+    assert n == 4 and len(rows) == 4 and rows[0] >= 1
+    eng.close()
+    assert _lib.ROW_HISTORY == 65536
