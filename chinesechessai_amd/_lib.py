@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(CSRC, "libxq_hip.so")
 SOURCES = [os.path.join(CSRC, "xq_engine.hip"), os.path.join(CSRC, "xq_conv.hip"), os.path.join(CSRC, "xq_replay.hip"),
            os.path.join(CSRC, "xq_tower.hip"), os.path.join(CSRC, "xq_policy.hip")]
 HEADERS = [os.path.join(CSRC, "xq_device.hpp"), os.path.join(CSRC, "xq_mfma.hpp"), os.path.join(CSRC, "xq_tower_probes.hpp"),
+           os.path.join(CSRC, "xq_tower1wa.hpp"), os.path.join(CSRC, "xq_tower1wa_body.inc"),
            os.path.join(_HERE, "..", "include", "xq_selfplay.h"), os.path.join(_HERE, "..", "include", "xq_debug.h")]
 
 MAX_MOVES = 128

@@ -792,6 +792,7 @@ static int tower_lds_opt_in(int bytes)
     return 0;
 }
 
+#include "xq_tower1wa.hpp"
 #if XQ_TOWER_PROBES
 #include "xq_tower_probes.hpp"
 #endif
@@ -823,6 +824,7 @@ static int launch_tower(void *stream, const void *planes, const void *w1, const 
     if (v == 36) XQ_TOWER_LAUNCH((k_tower16b<STAMP, 0, 2>), grid2, 256, LDS_BYTES);
     else if (v == 39) XQ_TOWER_LAUNCH((k_tower16b<STAMP, 0, 4>), grid4, 512, LDS_BYTES4);
     else if (v == 0) XQ_TOWER_LAUNCH((k_tower<STAMP>), grid2, 256, LDS_BYTES);
+    else if (v == 60) XQ_TOWER_LAUNCH((k_tower1wa<STAMP>), grid4, 256, LDS_BYTES1WA);                  // one wave per SIMD, assembly layer body
 #if XQ_TOWER_PROBES
     else if (v == 50) XQ_TOWER_LAUNCH((k_tower1w<STAMP>), grid4, 256, LDS_BYTES1W);                   // one wave per SIMD (results valid)
     else if (STAMP && v == 51) XQ_TOWER_LAUNCH((k_tower1w<true, 1>), grid4, 256, LDS_BYTES1W);       // ... no stage barriers (wrong results)

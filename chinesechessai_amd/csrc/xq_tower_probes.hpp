@@ -37,105 +37,13 @@ namespace {
 // ("+{a[0:3]}": the value has a VGPR class between the statements, 192 of them spill).
 // What hipcc does NOT do for an asm MFMA: insert the wait states a VALU-written source needs (amfma_guarded) or the ones
 // between an MFMA and a v_accvgpr_read of its result (s_nop block at the head of the epilogue).
-#define XQ_A8(b) "a" #b "0", "a" #b "1", "a" #b "2", "a" #b "3", "a" #b "4", "a" #b "5", "a" #b "6", "a" #b "7", "a" #b "8", "a" #b "9"
-#define XQ_AGPR_ALL() asm volatile("" ::: "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", XQ_A8(1), XQ_A8(2), XQ_A8(3), XQ_A8(4), \
-    XQ_A8(5), XQ_A8(6), XQ_A8(7), XQ_A8(8), XQ_A8(9), XQ_A8(10), XQ_A8(11), XQ_A8(12), XQ_A8(13), XQ_A8(14), XQ_A8(15), XQ_A8(16), \
-    XQ_A8(17), XQ_A8(18), "a190", "a191")
-// (the f32x4 & parameter is the compiler-visible stand-in of the tile: unused by this form)
-template <int T> __device__ __forceinline__ void amfma(f32x4 &, const bf16x8 &a, const bf16x8 &b)
-{
-    asm volatile("v_mfma_f32_16x16x32_bf16 a[%0:%1], %2, %3, a[%0:%1]" : : "n"(4 * T), "n"(4 * T + 3), "v"(a), "v"(b));
-}
-template <int T> __device__ __forceinline__ void amfma_guarded(f32x4 &, const bf16x8 &a, const bf16x8 &b)
-{
-    asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 a[%0:%1], %2, %3, a[%0:%1]" : : "n"(4 * T), "n"(4 * T + 3), "v"(a), "v"(b));
-}
-template <int T> __device__ __forceinline__ void aset(f32x4 &, const f32x4 &v)          // a[4T .. 4T+3] = v
-{
-    asm volatile("v_accvgpr_write_b32 a[%0], %4\n\tv_accvgpr_write_b32 a[%1], %5\n\tv_accvgpr_write_b32 a[%2], %6\n\tv_accvgpr_write_b32 a[%3], %7"
-                 : : "n"(4 * T), "n"(4 * T + 1), "n"(4 * T + 2), "n"(4 * T + 3), "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
-}
-template <int T> __device__ __forceinline__ f32x4 aget(const f32x4 &)
-{
-    float x0, x1, x2, x3;
-    asm volatile("v_accvgpr_read_b32 %0, a[%4]\n\tv_accvgpr_read_b32 %1, a[%5]\n\tv_accvgpr_read_b32 %2, a[%6]\n\tv_accvgpr_read_b32 %3, a[%7]"
-                 : "=v"(x0), "=v"(x1), "=v"(x2), "=v"(x3) : "n"(4 * T), "n"(4 * T + 1), "n"(4 * T + 2), "n"(4 * T + 3));
-    return f32x4{ x0, x1, x2, x3 };
-}
-// a[4T .. 4T+3] = 16 bytes of LDS at addr + OFF, straight into the accumulator (a layer's bias as its start value, no VALU
-// instruction).  An asm load is outside hipcc's s_waitcnt bookkeeping: the caller waits with await_lds() before the
-// registers are used; the compiler's own counted waits stay correct (extra operations in the in-order LDS queue only make
-// them conservative).
-template <int T, int OFF> __device__ __forceinline__ void aload(f32x4 &, int addr)
-{
-    asm volatile("ds_read_b128 a[%0:%1], %2 offset:%3" : : "n"(4 * T), "n"(4 * T + 3), "v"(addr), "n"(OFF) : "memory");
-}
-// compile-time loops over tiles
-template <int N0, int... Ms> __device__ __forceinline__ void amfma_col(std::integer_sequence<int, Ms...>, f32x4 *acc, const bf16x8 *fa, const bf16x8 &fb)
-{
-    (amfma<Ms * 6 + N0>(acc[Ms * 6 + N0], fa[Ms], fb), ...);
-}
-template <int... Ts> __device__ __forceinline__ void aset_all(std::integer_sequence<int, Ts...>, f32x4 *acc, const f32x4 &v) { (aset<Ts>(acc[Ts], v), ...); }
-
-// one MFMA of weight tile M on pixel tile n (n is a constant after unrolling: the switch folds away)
-template <int M> __device__ __forceinline__ void amfma_n(f32x4 *acc, int n, const bf16x8 &a, const bf16x8 &b)
-{
-    switch (n) {
-    case 0: amfma<M * 6 + 0>(acc[M * 6 + 0], a, b); break;
-    case 1: amfma<M * 6 + 1>(acc[M * 6 + 1], a, b); break;
-    case 2: amfma<M * 6 + 2>(acc[M * 6 + 2], a, b); break;
-    case 3: amfma<M * 6 + 3>(acc[M * 6 + 3], a, b); break;
-    case 4: amfma<M * 6 + 4>(acc[M * 6 + 4], a, b); break;
-    default: amfma<M * 6 + 5>(acc[M * 6 + 5], a, b); break;
-    }
-}
-
+// (the AGPR accumulator helpers - XQ_AGPR_ALL, amfma, aset, aget, aload, epi_pair ... - live in xq_tower1wa.hpp, which the
+// product kernel k_tower1wa shares with this experiment)
 #ifndef XQ_1W_DEBUG_WAIT
 #define XQ_1W_DEBUG_WAIT 0x0F74      // vmcnt(4); -DXQ_1W_DEBUG_WAIT=0x0070 drains everything at every stage barrier
 #endif
 constexpr int RING1W = 4;
 constexpr int LDS_BYTES1W = RING1W * WBUF_BYTES + 4 * ACT_BYTES + 256 + 2 * 512;
-
-template <int N0, int... Ms> __device__ __forceinline__ void aset_col(std::integer_sequence<int, Ms...>, f32x4 *acc, const f32x4 *b)
-{
-    (aset<Ms * 6 + N0>(acc[Ms * 6 + N0], b[Ms]), ...);
-}
-// two floats -> packed bf16 + ReLU without an asm statement (hipcc selects v_cvt_pk_bf16_f32 for the vector conversion and
-// can schedule it; the asm form of xq_mfma.hpp costs a boundary s_nop per use)
-__device__ __forceinline__ uint32_t pack_relu_bf16x2(float a, float b)
-{
-    typedef __attribute__((ext_vector_type(2))) float f32x2_t;
-    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
-    typedef __attribute__((ext_vector_type(2))) short s16x2_t;
-    const bf16x2_t h = __builtin_convertvector((f32x2_t){ a, b }, bf16x2_t);
-    s16x2_t v = *reinterpret_cast<const s16x2_t *>(&h);
-    v = __builtin_elementwise_max(v, (s16x2_t){ 0, 0 });
-    return *reinterpret_cast<const uint32_t *>(&v);
-}
-__device__ __forceinline__ void await_lds() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-// epilogue of pixel tile N of channel pair J: the lane's 8 consecutive channels (tiles 2J, 2J + 1) -> bf16 -> ReLU -> 16 bytes
-template <int J, int N> __device__ __forceinline__ uint4 epi_get(const f32x4 *acc)
-{
-    const f32x4 v0 = aget<(2 * J) * 6 + N>(acc[(2 * J) * 6 + N]), v1 = aget<(2 * J + 1) * 6 + N>(acc[(2 * J + 1) * 6 + N]);
-    return make_uint4(pack_relu_bf16x2(v0[0], v0[1]), pack_relu_bf16x2(v0[2], v0[3]),
-                      pack_relu_bf16x2(v1[0], v1[1]), pack_relu_bf16x2(v1[2], v1[3]));
-}
-// first half of a pair's epilogue: [x fragments in,] results out, next layer's bias into the accumulators
-template <int J, bool READ_X, int... Ns>
-__device__ __forceinline__ void epi_pair(std::integer_sequence<int, Ns...>, f32x4 *acc, const int *sb, bool tail_ok, int lbq, bf16x8 *xf)
-{
-    if constexpr (READ_X) ((xf[Ns] = lds_ld128(sb[Ns] ^ (J << 5))), ...);          // the block input x: the chunk this lane overwrites
-    uint4 pk[6];
-    ((pk[Ns] = epi_get<J, Ns>(acc)), ...);
-    ((Ns < 5 || tail_ok ? lds_st128(sb[Ns] ^ (J << 5), pk[Ns]) : (void)0), ...);
-    ((aload<(2 * J) * 6 + Ns, J * 128>(acc[(2 * J) * 6 + Ns], lbq), aload<(2 * J + 1) * 6 + Ns, J * 128 + 16>(acc[(2 * J + 1) * 6 + Ns], lbq)), ...);
-}
-// second half (first convolution of a block): + x through the matrix pipe, S . X with a 0/1 selector S
-template <int J, int... Ns>
-__device__ __forceinline__ void epi_skip(std::integer_sequence<int, Ns...>, f32x4 *acc, const bf16x8 *sel, const bf16x8 *xf)
-{
-    ((amfma_guarded<(2 * J) * 6 + Ns>(acc[(2 * J) * 6 + Ns], sel[0], xf[Ns]), amfma_guarded<(2 * J + 1) * 6 + Ns>(acc[(2 * J + 1) * 6 + Ns], sel[1], xf[Ns])), ...);
-}
 
 // ABL (timing probes, wrong results): 1 = no stage barriers, 2 = no vmcnt wait in front of them, 4 = no weight DMA
 template <bool STAMP, int ABL = 0>

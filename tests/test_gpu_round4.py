@@ -107,8 +107,9 @@ def test_refill_with_the_real_network_equals_lock_step_play(L):
             assert np.array_equal(out[k], ref_out[k]), (k, dedupe)
         for g in range(T):
             _same_game(rec[g], ref[g], (g, dedupe))
-        # fewer plies than three lock-step batches, and slots really restarted out of step
-        assert plies < 3 * 70 and len(seen) == plies
+        # never more plies than three lock-step batches (a slot that draws three 70-ply games needs them all), and slots
+        # really restarted out of step (below)
+        assert plies <= 3 * 70 and len(seen) == plies
         R = eng.rounds
         assert n_rounds == plies * R and len(rows) == n_rounds
         per = rows.reshape(plies, R)
