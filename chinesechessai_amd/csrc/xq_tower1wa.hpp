@@ -198,9 +198,10 @@ __device__ const LaneTab1WA g_lane_tab_1wa = make_lane_tab_1wa();
     XQ_V8(8), XQ_V8(9), XQ_V8(10), XQ_V8(11), XQ_V8(12), XQ_V8(13), XQ_V8(14), XQ_V8(15), XQ_V8(16), XQ_V8(17), XQ_V8(18), XQ_V8(19),   \
     XQ_V8(20), XQ_V8(21), XQ_V8(22), XQ_V8(23), XQ_V8(24), "v250", "v251", "v252", "v253",                                           \
     "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", XQ_A8(1), XQ_A8(2), XQ_A8(3), XQ_A8(4), XQ_A8(5), XQ_A8(6), XQ_A8(7),        \
-    XQ_A8(8), XQ_A8(9), XQ_A8(10), XQ_A8(11), XQ_A8(12), XQ_A8(13), XQ_A8(14), XQ_A8(15), XQ_A8(16), XQ_A8(17), XQ_A8(18), "a190", "a191", \
+    XQ_A8(8), XQ_A8(9), XQ_A8(10), XQ_A8(11), XQ_A8(12), XQ_A8(13), XQ_A8(14), XQ_A8(15), XQ_A8(16), XQ_A8(17), XQ_A8(18), XQ_A8(19), \
+    XQ_A8(20), XQ_A8(21), "a220", "a221", "a222", "a223",                                                                        \
     "s36", "s37", "s38", "s39", XQ_S8(4), XQ_S8(5), "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "vcc", "scc", "memory"
-static_assert(XQ_1WA_V_LAST == 253 && XQ_1WA_S_FIRST == 36 && XQ_1WA_S_LAST == 67, "clobber list of the layer body");
+static_assert(XQ_1WA_V_LAST == 253 && XQ_1WA_A_LAST == 223 && XQ_1WA_S_FIRST == 36 && XQ_1WA_S_LAST == 67, "clobber list of the layer body");
 
 template <bool STAMP>
 __global__ __launch_bounds__(256, 1) void k_tower1wa(TowerArgs A)

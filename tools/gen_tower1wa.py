@@ -66,6 +66,8 @@ V_PK = (210, 214)                  # 2 x 4 packed results
 V_XF = 218                         # 6 x 4: block input x of a pair (skip connection)
 V_ST = 242                         # stamps: 242..244
 V_LAST = 253
+A_BIAS = 192                       # a[192:223]: the next layer's bias row in accumulator layout, 4 registers per weight tile mt
+A_LAST = 223
 
 S_RSRC = 36                        # s[36:39] buffer resource of the weight stream
 S_BLK = 40                         # byte offset of the current block's first stage in the weight stream
@@ -115,9 +117,10 @@ class Emitter:
         return "XQ1WA_%d_%%=" % Emitter.NLABEL[0]      # %= : unique per asm statement instance
 
     # ---- primitives ------------------------------------------------------------------------------------------------------
-    def mfma(self, tile, a, b, want):
+    def mfma(self, tile, a, b, want, first=False):
         """acc[tile] += A x B.  a / b: fragment slot numbers, or 'sel0' / 'sel1' / 'xf<n>'.  want: what the model expects:
-        (layer tag, tap, ks) or ('skip', layer tag)"""
+        (layer tag, tap, ks) or ('skip', layer tag).  first: the tile's first MFMA of a layer - C is the layer's bias row
+        (a[A_BIAS + 4 mt : +3], loaded once per layer) instead of the tile itself: acc[tile] = A x B + bias."""
         def reg(x):
             if isinstance(x, int):
                 return SLOT(x)
@@ -127,8 +130,9 @@ class Emitter:
             n = int(x[2:])
             return "v[%d:%d]" % (V_XF + 4 * n, V_XF + 4 * n + 3)
         t = 4 * tile
-        self.add("v_mfma_f32_16x16x32_bf16 a[%d:%d], %s, %s, a[%d:%d]" % (t, t + 3, reg(a), reg(b), t, t + 3), "mfma",
-                 tile=tile, a=a, b=b, want=want)
+        c = A_BIAS + 4 * (tile // 6) if first else t
+        self.add("v_mfma_f32_16x16x32_bf16 a[%d:%d], %s, %s, a[%d:%d]" % (t, t + 3, reg(a), reg(b), c, c + 3), "mfma",
+                 tile=tile, a=a, b=b, want=want, first=first)
 
     def load_a(self, slot, lstage, kk, mt, want):
         """weight fragment mt of local stage lstage, K-step parity kk -> slot"""
@@ -261,9 +265,6 @@ class Emitter:
             if rx:
                 ops.append(("xread", J, n))
             ops.append(("store", J, n, st))
-            if not final:
-                ops.append(("bias", J, n, 0, bias_slot))
-                ops.append(("bias", J, n, 1, bias_slot))
         return ops
 
     def emit_op(self, op, lt, lt_next):
@@ -294,11 +295,10 @@ class Emitter:
                 self.add("v_xor_b32 v%d, %d, v%d" % (V_XT + n, J << 5, a), "valu", wr=[V_XT + n])
                 a = V_XT + n
             self.add("ds_write_b128 v%d, v[%d:%d]" % (a, V_PK[st], V_PK[st] + 3), "ldsw", store=(lt, J, n), data=V_PK[st])
-        elif kind == "bias":
-            _, J, n, o, bslot = op
-            tile = TILE(2 * J + o, n)
-            self.add("ds_read_b128 a[%d:%d], v%d offset:%d" % (4 * tile, 4 * tile + 3, V_LBQ, bslot * 512 + J * 128 + o * 16), "ldsr",
-                     dst="acc%d" % tile, src=("bias", bslot), want=("BIAS", lt_next, tile))
+        elif kind == "biasrow":
+            _, mt, bslot = op
+            self.add("ds_read_b128 a[%d:%d], v%d offset:%d" % (A_BIAS + 4 * mt, A_BIAS + 4 * mt + 3, V_LBQ, bslot * 512 + (mt >> 1) * 128 + (mt & 1) * 16),
+                     "ldsr", dst="bias%d" % mt, src=("bias", bslot), want=("BIASROW", lt_next, mt))
         else:
             raise ValueError(kind)
 
@@ -328,7 +328,9 @@ class Emitter:
                 lo += [("ldb", K, n) for n in range(6)]
             lo += [("lda", P, K, o, abuf[g] + o) for o in range(2)]
             loads_of[g] = lo
-            mfmas_of[g] = [("mfma", TILE(2 * P + o, n), abuf[g] + o, 6 * K + n, (lt_next, 0, K)) for n in range(6) for o in range(2)]
+            # a tile's first MFMA of the layer takes the bias row as C: the selector MFMA behind an even layer, else group (P, 0)
+            mfmas_of[g] = [("mfma", TILE(2 * P + o, n), abuf[g] + o, 6 * K + n, (lt_next, 0, K), (not rx) and K == 0)
+                           for n in range(6) for o in range(2)]
 
         def emit_f(f):
             if f[0] == "ldb":
@@ -350,18 +352,17 @@ class Emitter:
 
         def emit_m(m):
             if m[0] == "mfma":
-                self.mfma(m[1], m[2], m[3], m[4])
+                self.mfma(m[1], m[2], m[3], m[4], first=m[5])
             else:
-                self.mfma(m[1], "sel%d" % m[2], "xf%d" % m[3], ("skip", lt_next))
+                self.mfma(m[1], "sel%d" % m[2], "xf%d" % m[3], ("skip", lt_next), first=True)
 
-        # phase A: drain of pair 0 (nothing to put it under) with the DMA of the next layer's stage 3 spread over it
-        d0 = self.drain_ops(0, rx, bias_slot, False)
-        c = len(d0) // 5
-        for k in range(5):
-            for f in d0[k * c:(k + 1) * c if k < 4 else len(d0)]:
-                emit_f(f)
-            if k < 4:
-                emit_f(("dma", lbase_next + 3, k))
+        # the next layer's bias row into a[A_BIAS ..] (8 loads instead of one per tile: the tiles' first MFMAs take it as C)
+        for mt in range(8):
+            emit_f(("biasrow", mt, bias_slot))
+        # phase A: drain of pair 0 (nothing to put it under)
+        for f in self.drain_ops(0, rx, bias_slot, False):
+            emit_f(f)
+        dma3 = [("dma", lbase_next + 3, j) for j in range(4)]       # the next layer's stage 3: under the first MFMAs
         for J in range(4):
             groups = segs[J]
             # the segment's matrix items: [selector MFMAs of pair J,] then its groups; the loads of a group are emitted
@@ -375,6 +376,9 @@ class Emitter:
                 emit_f(f)
             if J < 3:
                 low = self.drain_ops(J + 1, rx, bias_slot, False)          # low-priority fillers: the next pair's drain
+                if J < 2:                                                  # ... and two pieces of the stage-3 DMA
+                    h = len(low) // 3
+                    low = low[:h] + [dma3.pop(0)] + low[h:2 * h] + [dma3.pop(0)] + low[2 * h:]
                 n_m = sum(len(it[1]) for it in items)
                 n_la = sum(len(it[2]) for it in items[1:])
                 per_gap = -(-(len(low) + n_la) // n_m)
@@ -532,7 +536,7 @@ def insert_lgkm_waits(linear):
     for ins in linear:
         k = ins.kind
         if k == "mfma":
-            keys = [("f", ins.m["a"]), ("f", ins.m["b"]), ("acc", ins.m["tile"])]
+            keys = [("f", ins.m["a"]), ("f", ins.m["b"]), ("bias", ins.m["tile"] // 6) if ins.m.get("first") else ("acc", ins.m["tile"])]
             need(keys)
         elif k == "lgkm0":
             retired = nl
@@ -540,7 +544,8 @@ def insert_lgkm_waits(linear):
             nl += 1
         if k == "ldsr":
             d = ins.m["dst"]
-            key = ("acc", int(d[3:])) if isinstance(d, str) and d.startswith("acc") else ("f", d)
+            key = ("acc", int(d[3:])) if isinstance(d, str) and d.startswith("acc") else (
+                ("bias", int(d[4:])) if isinstance(d, str) and d.startswith("bias") else ("f", d))
             pend[key] = nl
             nl += 1
         elif k == "ldsw":
@@ -569,6 +574,7 @@ def check_and_fill(linear, nblocks):
     bias_slot = {0: [None, True, []], 1: [0, True, []]}      # slot -> [layer whose bias, landed for all, read op indices]
     frag = {}                  # slot / 'xf<n>' -> (tag, lds op index)
     acc = {t: {"hist": [("BIAS", 0)], "read": set(), "last_mfma": -10 ** 9, "pending": None} for t in range(48)}
+    biasreg = {}               # weight tile mt -> (layer whose bias row a[A_BIAS + 4 mt ..] holds, lds op index)
     rd = {}                    # vgpr -> (tile, comp, layer)
     pk = {}                    # vgpr -> ("cvt" | "relu", tile, comps, layer)
     nl, retired = 0, 0         # LDS queue
@@ -632,13 +638,14 @@ def check_and_fill(linear, nblocks):
                 frag[dst] = (want, nl)
             elif src[0] == "bias":
                 _, bs = src
-                _, Lb, tile = want
+                _, Lb, mt = want
                 if bias_slot[bs][0] != Lb or not bias_slot[bs][1]:
                     fail(i, "bias read of layer %d from slot %d which holds %s (landed %s)" % (Lb, bs, bias_slot[bs][0], bias_slot[bs][1]))
-                a = acc[tile]
-                if a["read"] != {0, 1, 2, 3}:
-                    fail(i, "bias load into tile %d before it was drained (%s)" % (tile, a["read"]))
-                a["hist"], a["read"], a["pending"] = [("BIAS", Lb)], set(), nl
+                # the row it replaces must not be needed any more: every tile of weight tile mt has had its first MFMA
+                old = biasreg.get(mt)
+                if old is not None and any(acc[TILE(mt, n)]["hist"][0] != ("BIAS", old[0]) for n in range(6)):
+                    fail(i, "bias row of weight tile %d (layer %d) replaced before every tile took it" % (mt, old[0]))
+                biasreg[mt] = (Lb, nl)
                 bias_slot[bs][2].append(nl)
             nl += 1
         elif k == "ldsw":
@@ -655,10 +662,18 @@ def check_and_fill(linear, nblocks):
         elif k == "mfma":
             tile, want = m["tile"], m["want"]
             a = acc[tile]
-            if a["pending"] is not None:
-                if a["pending"] >= retired:
-                    fail(i, "MFMA on tile %d whose bias load has not been waited for" % tile)
-                a["pending"] = None
+            if m.get("first"):
+                Ln = want[1] if want[0] == "skip" else want[0]
+                br = biasreg.get(tile // 6)
+                if br is None or br[0] != Ln:
+                    fail(i, "first MFMA of tile %d for layer %d: bias registers hold %s" % (tile, Ln, br))
+                if br[1] >= retired:
+                    fail(i, "first MFMA of tile %d: bias row not waited for" % tile)
+                if a["read"] != {0, 1, 2, 3}:
+                    fail(i, "first MFMA of tile %d overwrites an accumulator that was not drained (%s)" % (tile, a["read"]))
+                a["hist"], a["read"] = [("BIAS", Ln)], set()
+            elif a["read"]:
+                fail(i, "MFMA accumulates onto tile %d after it was (partly) read out" % tile)
             if want[0] == "skip":
                 L = want[1]
                 if frag.get(m["b"], (None,))[0] != ("XIN", L - 1, tile // 12, tile % 6):
@@ -870,8 +885,8 @@ def generate():
         parts.append("// %s: %d instructions (%d MFMAs per loop body + first tap + last epilogue), %d exact lgkmcnt waits; %d instructions of a 3-block instance checked\n"
                      % (name, stats["instructions"], stats["mfma"], stats["lgkm_waits"], stats["checked"]))
         parts.append(as_c_string(lines, name))
-    consts = ("#define XQ_1WA_LDS_BYTES %d\n#define XQ_1WA_JUNK %d\n#define XQ_1WA_TAB_DWORDS %d\n#define XQ_1WA_V_LAST %d\n#define XQ_1WA_S_FIRST %d\n#define XQ_1WA_S_LAST %d\n"
-              % (LDS_TOTAL, JUNK, TAB_DWORDS, V_LAST, S_RSRC, S_LAST))
+    consts = ("#define XQ_1WA_LDS_BYTES %d\n#define XQ_1WA_JUNK %d\n#define XQ_1WA_TAB_DWORDS %d\n#define XQ_1WA_V_LAST %d\n#define XQ_1WA_A_LAST %d\n#define XQ_1WA_S_FIRST %d\n#define XQ_1WA_S_LAST %d\n"
+              % (LDS_TOTAL, JUNK, TAB_DWORDS, V_LAST, A_LAST, S_RSRC, S_LAST))
     parts.append(consts)
     return "".join(parts), allstats
 
