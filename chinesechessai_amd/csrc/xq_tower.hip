@@ -10,9 +10,14 @@
 // The per-layer kernels of xq_conv.hip spend 18 % of a workgroup's time in those global
 // prologue / epilogue phases (tools/bench_conv.py stamps); here only the weight stream is left.
 //
-// Same tiling as k_conv3x3_b variant B: a wave = (board, output-channel half), wave tile 96 pixels x 64 channels,
-// weights streamed by LDS-DMA in K-slices [128 cout][64 cin] through a double buffer.  Builds (xq_tower_set_variant):
-//   k_tower16b<NB = 4> (39)  the default from 2,048 boards up (round 3): 4 boards per 512-thread workgroup, one
+// Builds (xq_tower_set_variant):
+//   k_tower1wa (60)      the default from 2,048 boards up (round 4, xq_tower1wa.hpp): ONE wave per SIMD, a wave = a board x all 128
+//                        output channels (wave tile 128 x 96, accumulators on a[0:191]), 4 boards per 256-thread workgroup, ring
+//                        of 4 weight stages; the residual tower is one generated, symbolically checked asm statement in which a
+//                        layer's epilogue runs under the next layer's first tap.  Same bits as k_tower16b
+// k_tower16b / k_tower: the tiling of k_conv3x3_b variant B: a wave = (board, output-channel half), wave tile 96 pixels x 64
+// channels, weights streamed by LDS-DMA in K-slices [128 cout][64 cin] through a double buffer:
+//   k_tower16b<NB = 4> (39)  round 3's default from 2,048 boards up: 4 boards per 512-thread workgroup, one
 //                        workgroup per CU, ONE weight stream per 4 boards (half the L2 -> LDS traffic of the 2-board
 //                        form); all 8 waves run in lock-step through the stage barriers.  Costs cycles (412 k against
 //                        376 k per 4 boards) and wins them back in clock (2.06-2.10 against 1.85-1.90 GHz): 2-3 % faster
@@ -771,9 +776,9 @@ __global__ __launch_bounds__(NB * 128, 2) void k_tower16b(TowerArgs A)
 
 }  // namespace
 
-static int g_tower_variant = -1;    // -1 = automatic: k_tower16b<NB = 4> from 2,048 boards up, k_tower16b<NB = 2> below;
-                                    // 36 = k_tower16b, 2 boards per workgroup; 39 = 4 boards per workgroup; 0 = k_tower (32x32x16 comparison build);
-                                    // 30, 31, 41, 43, 50 = timing probes and experiments (XQ_TOWER_PROBES builds)
+static int g_tower_variant = -1;    // -1 = automatic: k_tower1wa from 2,048 boards up, k_tower16b<NB = 2> below;
+                                    // 60 = k_tower1wa; 36 = k_tower16b, 2 boards per workgroup; 39 = 4 boards per workgroup; 0 = k_tower (32x32x16
+                                    // comparison build); 30, 31, 41, 43, 50, 61..66 = timing probes and experiments (XQ_TOWER_PROBES builds)
 // diagnostic switch (include/xq_debug.h): the builds compute the same function (36, 39 and 50 to the bit)
 extern "C" void xq_tower_set_variant(int v) { g_tower_variant = v; }
 
@@ -819,14 +824,22 @@ static int launch_tower(void *stream, const void *planes, const void *w1, const 
     // higher clock, worth 2-3 % from 2,048 boards up; below that one 512-thread workgroup per CU leaves CUs empty
     // (512 boards: 0.19 against 0.13 ms).  Same bits either way.  (n_boards is the launch's capacity: with a row map
     // the rows really present may be fewer, the choice is then not optimal, never wrong.)
+    // Round 4: from 2,048 boards up the default is k_tower1wa (one wave per SIMD, the residual tower as one hand-written asm
+    // statement): the same bits, 1.0-1.6 % faster than the 4-board k_tower16b on the three boxes it was timed on.
     int v = g_tower_variant;
-    if (v < 0) v = n_boards >= 2048 ? 39 : 36;
+    if (v < 0) v = n_boards >= 2048 ? 60 : 36;
     if (v == 36) XQ_TOWER_LAUNCH((k_tower16b<STAMP, 0, 2>), grid2, 256, LDS_BYTES);
     else if (v == 39) XQ_TOWER_LAUNCH((k_tower16b<STAMP, 0, 4>), grid4, 512, LDS_BYTES4);
     else if (v == 0) XQ_TOWER_LAUNCH((k_tower<STAMP>), grid2, 256, LDS_BYTES);
     else if (v == 60) XQ_TOWER_LAUNCH((k_tower1wa<STAMP>), grid4, 256, LDS_BYTES1WA);                  // one wave per SIMD, assembly layer body
 #if XQ_TOWER_PROBES
     else if (v == 50) XQ_TOWER_LAUNCH((k_tower1w<STAMP>), grid4, 256, LDS_BYTES1W);                   // one wave per SIMD (results valid)
+    else if (STAMP && v == 61) XQ_TOWER_LAUNCH((k_tower1wa<true, 1>), grid4, 256, LDS_BYTES1WA);     // k_tower1wa timing-only bodies (wrong results):
+    else if (STAMP && v == 62) XQ_TOWER_LAUNCH((k_tower1wa<true, 2>), grid4, 256, LDS_BYTES1WA);     //   drains read VGPRs / no stores / no drain /
+    else if (STAMP && v == 63) XQ_TOWER_LAUNCH((k_tower1wa<true, 3>), grid4, 256, LDS_BYTES1WA);     //   no weight DMA / no barriers / none of the three
+    else if (STAMP && v == 64) XQ_TOWER_LAUNCH((k_tower1wa<true, 4>), grid4, 256, LDS_BYTES1WA);
+    else if (STAMP && v == 65) XQ_TOWER_LAUNCH((k_tower1wa<true, 5>), grid4, 256, LDS_BYTES1WA);
+    else if (STAMP && v == 66) XQ_TOWER_LAUNCH((k_tower1wa<true, 6>), grid4, 256, LDS_BYTES1WA);
     else if (STAMP && v == 51) XQ_TOWER_LAUNCH((k_tower1w<true, 1>), grid4, 256, LDS_BYTES1W);       // ... no stage barriers (wrong results)
     else if (STAMP && v == 52) XQ_TOWER_LAUNCH((k_tower1w<true, 3>), grid4, 256, LDS_BYTES1W);       // ... no barriers, no vmcnt waits
     else if (STAMP && v == 53) XQ_TOWER_LAUNCH((k_tower1w<true, 7>), grid4, 256, LDS_BYTES1W);       // ... and no weight DMA

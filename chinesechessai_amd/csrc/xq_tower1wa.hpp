@@ -16,6 +16,9 @@
 // Reference ops: neural_network.py:54-66,181-187 with eval-mode BatchNorm folded.
 #pragma once
 #include "xq_tower1wa_body.inc"
+#if XQ_TOWER_PROBES
+#include "xq_tower1wa_abl.inc"      // timing-only bodies (wrong results): python tools/gen_tower1wa.py --ablations
+#endif
 
 namespace {
 
@@ -200,10 +203,11 @@ __device__ const LaneTab1WA g_lane_tab_1wa = make_lane_tab_1wa();
     "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", XQ_A8(1), XQ_A8(2), XQ_A8(3), XQ_A8(4), XQ_A8(5), XQ_A8(6), XQ_A8(7),        \
     XQ_A8(8), XQ_A8(9), XQ_A8(10), XQ_A8(11), XQ_A8(12), XQ_A8(13), XQ_A8(14), XQ_A8(15), XQ_A8(16), XQ_A8(17), XQ_A8(18), XQ_A8(19), \
     XQ_A8(20), XQ_A8(21), "a220", "a221", "a222", "a223",                                                                        \
-    "s36", "s37", "s38", "s39", XQ_S8(4), XQ_S8(5), "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "vcc", "scc", "memory"
-static_assert(XQ_1WA_V_LAST == 253 && XQ_1WA_A_LAST == 223 && XQ_1WA_S_FIRST == 36 && XQ_1WA_S_LAST == 67, "clobber list of the layer body");
+    "s36", "s37", "s38", "s39", XQ_S8(4), XQ_S8(5), "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "vcc", "scc", "memory"
+static_assert(XQ_1WA_V_LAST == 253 && XQ_1WA_A_LAST == 223 && XQ_1WA_S_FIRST == 36 && XQ_1WA_S_LAST == 69, "clobber list of the layer body");
 
-template <bool STAMP>
+// ABL (probes builds, stamped, wrong results): one of the timing-only bodies of xq_tower1wa_abl.inc
+template <bool STAMP, int ABL = 0>
 __global__ __launch_bounds__(256, 1) void k_tower1wa(TowerArgs A)
 {
     constexpr int NB = 4, PPW = 4;                                       // boards = waves, weight pieces per wave and stage
@@ -348,6 +352,16 @@ __global__ __launch_bounds__(256, 1) void k_tower1wa(TowerArgs A)
         const float *bias2 = A.bias + 256;                              // row 2 = tower layer 1
         const unsigned long long *st = STAMP ? A.stamps + (size_t)blockIdx.x * 64 + 3 : nullptr;
         const int wt_bytes = nlayers * 9 * COUT * COUT * 2;
+#if XQ_TOWER_PROBES
+#define XQ_1WA_RUN_ABL(K) asm volatile(XQ_1WA_BODY_ABL##K : : "s"(tab), "s"(A.wt), "s"(wt_bytes), "s"(bias2), "s"(A.nblocks), "s"(wave), "s"(st), "v"(tid) : XQ_1WA_CLOBBERS)
+        if constexpr (ABL == 1) XQ_1WA_RUN_ABL(1);
+        else if constexpr (ABL == 2) XQ_1WA_RUN_ABL(2);
+        else if constexpr (ABL == 3) XQ_1WA_RUN_ABL(3);
+        else if constexpr (ABL == 4) XQ_1WA_RUN_ABL(4);
+        else if constexpr (ABL == 5) XQ_1WA_RUN_ABL(5);
+        else if constexpr (ABL == 6) XQ_1WA_RUN_ABL(6);
+        else
+#endif
         if constexpr (STAMP)
             asm volatile(XQ_1WA_BODY_STAMPED
                          :

@@ -81,8 +81,15 @@ S_WAVE = 60
 S_T = 61                           # temporaries s61, s62, s63
 S_TIME = 64                        # s[64:65] s_memtime
 S_STAMP = 66                       # s[66:67] stamp slot 3 + 4 blk of this workgroup
-S_LAST = 67
+S_STAMP0 = 68                      # s[68:69] stamp slot 0 of this workgroup (fine stamps inside a transition)
+S_LAST = 69
 BLOCK_BYTES = 18 * 32768           # weight bytes of a block = 36 stages
+
+
+# timing-only ablations (wrong results; bodies for the probes library, never checked, never in the product):
+# "noaccread" drains read VGPRs instead of accumulators, "nostore" no ds_write in the drains, "nodrain" no drain at all,
+# "nodma" no weight DMA, "nobar" no s_barrier
+ABL = set()
 
 
 class Ins:
@@ -156,7 +163,10 @@ class Emitter:
             self.add("s_min_u32 s%d, s%d, s%d" % (S_T, S_T, S_MAX + j))
         self.add("s_add_u32 m0, s%d, 0x%x" % (S_LDST + j, rs * WBUF))
         self.add("s_nop 0")
-        self.add("buffer_load_dwordx4 v%d, s[%d:%d], s%d offen lds" % (V_WSRC + (j & 1), S_RSRC, S_RSRC + 3, S_T), "dma", lstage=lstage, piece=j)
+        if "nodma" in ABL:
+            self.add("s_nop 0", "dma", lstage=lstage, piece=j)
+        else:
+            self.add("buffer_load_dwordx4 v%d, s[%d:%d], s%d offen lds" % (V_WSRC + (j & 1), S_RSRC, S_RSRC + 3, S_T), "dma", lstage=lstage, piece=j)
 
     def bias_dma(self, slot, lrow, skip_if_last_block=False):
         """wave 1, lanes 0..31: the next bias row -> bias slot `slot` (lrow: tag of the layer whose bias it is)"""
@@ -178,9 +188,10 @@ class Emitter:
         """own pieces of local stage `landed` and of everything older have arrived (exact vmcnt filled in later), then the
         workgroup barrier"""
         self.add("s_waitcnt vmcnt(?)", "vmwait", landed=landed)
-        self.add("s_barrier", "barrier", note=note)
+        self.add("s_nop 0" if "nobar" in ABL else "s_barrier", "barrier", note=note)
 
-    def stamp(self, k):
+    def stamp(self, k, absolute=False):
+        """stamped bodies: s_memtime -> stamp slot 3 + 4 blk + k of the workgroup (absolute: slot k)"""
         if not self.stamps:
             return
         self.add("s_memtime s[%d:%d]" % (S_TIME, S_TIME + 1), "smem")
@@ -189,7 +200,8 @@ class Emitter:
         self.add("v_mov_b32 v%d, s%d" % (V_ST, S_TIME), "valu", wr=[V_ST])
         self.add("v_mov_b32 v%d, s%d" % (V_ST + 1, S_TIME + 1), "valu", wr=[V_ST + 1])
         self.add("v_mov_b32 v%d, 0" % (V_ST + 2), "valu", wr=[V_ST + 2])
-        self.add("global_store_dwordx2 v%d, v[%d:%d], s[%d:%d] offset:%d" % (V_ST + 2, V_ST, V_ST + 1, S_STAMP, S_STAMP + 1, k * 8), "gstore")
+        base = S_STAMP0 if absolute else S_STAMP
+        self.add("global_store_dwordx2 v%d, v[%d:%d], s[%d:%d] offset:%d" % (V_ST + 2, V_ST, V_ST + 1, base, base + 1, k * 8), "gstore")
         self.add("s_mov_b64 exec, -1")
 
     # ---- one regular tap: 4 K-steps = 2 weight stages ------------------------------------------------------------------------
@@ -269,6 +281,8 @@ class Emitter:
 
     def emit_op(self, op, lt, lt_next):
         kind = op[0]
+        if "nodrain" in ABL and kind != "biasrow":
+            return
         if kind == "xread":
             _, J, n = op
             a = V_SB + n
@@ -280,7 +294,10 @@ class Emitter:
         elif kind == "accread":
             _, J, n, k, st = op
             tile = TILE(2 * J + (k >> 2), n)
-            self.add("v_accvgpr_read_b32 v%d, a%d" % (V_RD[st] + k, 4 * tile + (k & 3)), "valu", wr=[V_RD[st] + k], accread=(tile, k & 3), layer=lt)
+            if "noaccread" in ABL:
+                self.add("v_mov_b32 v%d, v%d" % (V_RD[st] + k, V_SEL + (k & 3)), "valu", wr=[V_RD[st] + k], accread=(tile, k & 3), layer=lt)
+            else:
+                self.add("v_accvgpr_read_b32 v%d, a%d" % (V_RD[st] + k, 4 * tile + (k & 3)), "valu", wr=[V_RD[st] + k], accread=(tile, k & 3), layer=lt)
         elif kind == "cvt":
             _, J, n, k, st = op
             self.add("v_cvt_pk_bf16_f32 v%d, v%d, v%d" % (V_PK[st] + k, V_RD[st] + 2 * k, V_RD[st] + 2 * k + 1), "valu",
@@ -294,7 +311,10 @@ class Emitter:
             if J:
                 self.add("v_xor_b32 v%d, %d, v%d" % (V_XT + n, J << 5, a), "valu", wr=[V_XT + n])
                 a = V_XT + n
-            self.add("ds_write_b128 v%d, v[%d:%d]" % (a, V_PK[st], V_PK[st] + 3), "ldsw", store=(lt, J, n), data=V_PK[st])
+            if "nostore" in ABL:
+                self.add("s_nop 0", "ldsw_skipped", store=(lt, J, n), data=V_PK[st])
+            else:
+                self.add("ds_write_b128 v%d, v[%d:%d]" % (a, V_PK[st], V_PK[st] + 3), "ldsw", store=(lt, J, n), data=V_PK[st])
         elif kind == "biasrow":
             _, mt, bslot = op
             self.add("ds_read_b128 a[%d:%d], v%d offset:%d" % (A_BIAS + 4 * mt, A_BIAS + 4 * mt + 3, V_LBQ, bslot * 512 + (mt >> 1) * 128 + (mt & 1) * 16),
@@ -419,6 +439,200 @@ class Emitter:
                 assert not low, low
         self.stamp(stamp_k)
 
+    # ---- the transition between two layers: last tap of layer lt, its epilogue, first tap of layer lt_next ------------------------
+    def transition(self, lt, lt_next, lbase, lbase_next, rx, bias_slot, bias_fetch_slot, bias_fetch_tag, bias_skip_last, stamp_k,
+                   final=False, lead=20, fine=None):
+        """Tap 8 of layer lt is issued in two halves by output channel: h1 = weight tiles 0..3 (pairs 0, 1) over ks 0..3, then
+        h2 = weight tiles 4..7 - every accumulator still sees (tap 8: ks 0, 1, 2, 3).  Pairs 0 and 1 are complete behind h1, so
+        their drains D(0), D(1) issue in the gaps of h2's 96 MFMAs; D(2) and D(3) issue under the first MFMA groups of the next
+        layer's tap 0 (group (P, K) = output pair P x input group K, ready once pairs P and K are drained).  The drains' ~430
+        VALU and ~60 LDS instructions then sit beside ~200 MFMAs instead of none.
+        A list scheduler places everything: the MFMA sequence is fixed; each fragment load is emitted `lead` MFMAs ahead of its
+        first use, not before the data exists (a barrier published the stage / the drain stored the rows), into a free slot;
+        fillers are spread evenly over the MFMA range they are anchored to."""
+        self.comment("---- transition: tap 8 of layer %s, its epilogue, tap 0 of layer %s" % (lt, lt_next))
+        M = []                                   # matrix sequence: ("mfma", tile, Aid, Bid, want, first) | ("sel", tile, o, n) | ("bar", name, landed)
+        tap = 8
+        def A8(ks, mt): return ("A", lt, tap, ks, mt)
+        def B8(ks, n, h): return ("B", lt, tap, ks, n, h)
+        def An(K, mt): return ("A", lt_next, 0, K, mt)
+        def Bn(K, n, seg): return ("B", lt_next, 0, K, n, seg)
+        marks = {}
+        for h, mts in ((1, range(0, 4)), (2, range(4, 8))):
+            for ks in range(4):
+                for n in range(6):
+                    for mt in mts:
+                        M.append(("mfma", TILE(mt, n), A8(ks, mt), B8(ks, n, h), (lt, tap, ks), False))
+                    if h == 1 and ks == 1 and n == 0:
+                        M.append(("bar", "B16", lbase + 17))           # stage 17 has landed; every wave has left stage 15
+                if h == 2 and ks == 1:
+                    M.append(("bar", "BH", None if final else lbase_next))      # every wave has left stage 16 (its slot: the next layer's stage 2)
+                    marks["h2mid"] = len([m for m in M if m[0] not in ("bar", "stamp")])
+                    if rx:
+                        M += [("sel", TILE(o, n), o, n) for n in range(6) for o in range(2)]     # pair 0: x + bias (D(0) is done)
+        n_h = len([m for m in M if m[0] not in ("bar", "stamp")])
+        if fine is not None:
+            # fine stamps (absolute slots fine .. fine + 4): behind h1, h2, the first, the second group segment (the section's own
+            # stamp follows the third)
+            k = [i for i, m in enumerate(M) if m[0] == "mfma"][95]
+            M.insert(k + 1, ("stamp", fine))
+            M.append(("stamp", fine + 1))
+        segs = [[(0, 0), (1, 0), (0, 1), (1, 1)], [(2, 0), (2, 1), (0, 2), (1, 2), (2, 2)], [(3, 0), (3, 1), (3, 2), (0, 3), (1, 3), (2, 3), (3, 3)]]
+        seg_start = []
+        if not final:
+            M.append(("bar", "BE", lbase_next + 1))                     # every wave has left stage 17; the next layer's stages 0, 1 have landed
+            for si, sg in enumerate(segs):
+                if fine is not None and si > 0:
+                    M.append(("stamp", fine + 1 + si))
+                seg_start.append(len([m for m in M if m[0] not in ("bar", "stamp")]))
+                if rx:
+                    J = si + 1
+                    M += [("sel", TILE(2 * J + o, n), o, n) for n in range(6) for o in range(2)]
+                for (P, K) in sg:
+                    M += [("mfma", TILE(2 * P + o, n), An(K, 2 * P + o), Bn(K, n, si), (lt_next, 0, K), (not rx) and K == 0)
+                          for n in range(6) for o in range(2)]
+                    if (P, K) == (3, 1):
+                        M.append(("bar", "BX", lbase_next + 2))         # every wave has left the next layer's stage 0; its stage 2 has landed
+                        marks["bx"] = len([m for m in M if m[0] not in ("bar", "stamp")])
+        nm = len([m for m in M if m[0] not in ("bar", "stamp")])
+        # gap index of every matrix item; barrier positions
+        gap_of_bar = {}
+        g = 0
+        for m in M:
+            if m[0] == "bar":
+                gap_of_bar[m[1]] = g
+            elif m[0] != "stamp":
+                g += 1
+        # ---- fillers anchored to gap ranges [s, e)
+        fill_at = {}
+        def spread(ops, s0, e0):
+            n = len(ops)
+            for k, op in enumerate(ops):
+                fill_at.setdefault(s0 + (k * (e0 - s0)) // max(n, 1), []).append(op)
+            return e0
+        h2s = 96
+        mid = marks["h2mid"]                                             # first gap behind h2's ks 1
+        d_end = {}
+        spread([("biasrow", mt, bias_slot) for mt in range(8)] if not final else [], 0, 8)
+        if rx:
+            d_end[0] = spread(self.drain_ops(0, rx, bias_slot, final), h2s, mid - 2)
+            d_end[1] = spread(self.drain_ops(1, rx, bias_slot, final), mid + 12, n_h)
+        else:
+            d_end[0] = spread(self.drain_ops(0, rx, bias_slot, final), h2s, mid)
+            d_end[1] = spread(self.drain_ops(1, rx, bias_slot, final), mid, n_h)
+        if not final:
+            sel = 12 if rx else 0
+            d_end[2] = spread(self.drain_ops(2, rx, bias_slot, final), seg_start[0] + sel, seg_start[1])
+            d_end[3] = spread(self.drain_ops(3, rx, bias_slot, final), seg_start[1] + sel, seg_start[2])
+            # weight DMA: stage 1' behind B16 (slot of stage 15), 2' behind BH (slot of 16), 3' behind BE (slot of 17), 4' behind BX
+            spread([("dma", lbase + 19, j) for j in range(4)], gap_of_bar["B16"] + 2, gap_of_bar["B16"] + 40)
+            spread([("dma", lbase + 20, j) for j in range(4)], gap_of_bar["BH"] + 2, gap_of_bar["BH"] + 40)
+            spread([("dma", lbase + 21, j) for j in range(4)], gap_of_bar["BE"] + 2, gap_of_bar["BE"] + 40)
+            spread([("dma", lbase + 22, j) for j in range(4)] + [("biasdma",)], gap_of_bar["BX"] + 1, gap_of_bar["BX"] + 30)
+        # ---- fragments: first / last use, earliest load position
+        first_use, last_use = {}, {}
+        g = 0
+        for m in M:
+            if m[0] == "mfma":
+                for fid in (m[2], m[3]):
+                    first_use.setdefault(fid, g)
+                    last_use[fid] = g
+            if m[0] not in ("bar", "stamp"):
+                g += 1
+        earliest = {}
+        for fid in first_use:
+            e0 = 0
+            if fid[0] == "A" and fid[1] == lt and fid[3] >= 2:
+                e0 = gap_of_bar["B16"]                                   # stage 17
+            if fid[1] == lt_next and not final:
+                e0 = gap_of_bar["BE"]
+                if fid[0] == "B":
+                    e0 = max(e0, d_end[fid[3]])                          # the rows of input group K are stored
+            earliest[fid] = e0
+        # what tap 7's last K-step prefetched: (tap 8, ks 0) into slots 0..13
+        slot_of = {}
+        free = list(range(30))
+        for mt in range(4):
+            slot_of[A8(0, mt)] = mt
+        for n in range(6):
+            slot_of[B8(0, n, 1)] = 8 + n
+        for sl in list(range(4)) + list(range(8, 14)):
+            free.remove(sl)
+        load_at = {}
+        for fid in first_use:
+            if fid in slot_of:
+                continue
+            load_at.setdefault(max(earliest[fid], first_use[fid] - lead), []).append(fid)
+        # the next tap's first K-step into buffer 0 (slots 0..13), behind BX
+        pf = []
+        if not final:
+            pf = [("pfa", m) for m in range(8)] + [("pfb", n) for n in range(6)]
+            spread(pf, gap_of_bar["BX"] + 31, nm - 6)
+
+        def emit_load(fid):
+            # the slot freed longest ago; fragments still alive behind B_X stay out of slots 0..13, which must be free for the
+            # next tap's prefetch at the end
+            cand = [x for x in free if x >= 14] if (not final and last_use[fid] >= gap_of_bar["BX"] + 31) else free
+            assert cand, ("out of fragment slots", fid, g)
+            sl = cand[0]
+            free.remove(sl)
+            slot_of[fid] = sl
+            if fid[0] == "A":
+                _, L, tp, ks, mt = fid
+                base = lbase if L == lt else lbase_next
+                self.load_a(sl, base + 2 * tp + (ks >> 1), ks & 1, mt, (L, tp, ks, mt))
+            else:
+                _, L, tp, ks, n, _h = fid
+                self.load_b(sl, tp, ks, n, (L, tp, ks, n))
+
+        def emit_filler(f):
+            if f[0] == "dma":
+                self.dma_piece(f[1], f[2])
+            elif f[0] == "biasdma":
+                self.bias_dma(bias_fetch_slot, bias_fetch_tag, bias_skip_last)
+            elif f[0] == "pfa":
+                assert f[1] in free, ("prefetch slot busy", f, sorted(free))
+                free.remove(f[1])
+                self.load_a(f[1], lbase_next + 2, 0, f[1], (lt_next, 1, 0, f[1]))
+            elif f[0] == "pfb":
+                assert 8 + f[1] in free, ("prefetch slot busy", f, sorted(free))
+                free.remove(8 + f[1])
+                self.load_b(8 + f[1], 1, 0, f[1], (lt_next, 1, 0, f[1]))
+            else:
+                self.emit_op(f, lt, lt_next)
+
+        g = 0
+        for m in M:
+            if m[0] == "bar":
+                self.barrier(m[2], m[1])
+                continue
+            if m[0] == "stamp":
+                self.stamp(m[1], absolute=True)
+                continue
+            for fid in load_at.get(g, []):
+                emit_load(fid)
+            if m[0] == "mfma":
+                assert m[2] in slot_of and m[3] in slot_of, ("fragment not loaded", m, g)
+                self.mfma(m[1], slot_of[m[2]], slot_of[m[3]], m[4], first=m[5])
+                for fid in (m[2], m[3]):
+                    if last_use[fid] == g:
+                        free.append(slot_of[fid])
+            else:
+                self.mfma(m[1], "sel%d" % m[2], "xf%d" % m[3], ("skip", lt_next), first=True)
+            for f in fill_at.get(g, []):
+                emit_filler(f)
+            g += 1
+        for gg in sorted(k for k in fill_at if k >= g):
+            for f in fill_at[gg]:
+                emit_filler(f)
+        if final:
+            for J in (2, 3):
+                for op in self.drain_ops(J, False, 0, True):
+                    self.emit_op(op, lt, None)
+            self.barrier(None, "BF")
+            self.add("s_waitcnt lgkmcnt(0)", "lgkm0")
+        self.stamp(stamp_k)
+
     def final_drain(self, lt, stamp_k):
         self.comment("---- epilogue of the last layer")
         self.barrier(None, "BF")
@@ -442,6 +656,8 @@ def sec_head(stamps):
     e.add("s_mov_b32 s%d, %%5" % S_WAVE)
     e.add("s_mov_b64 s[%d:%d], %%3" % (S_BIASP, S_BIASP + 1))
     e.add("s_mov_b64 s[%d:%d], %%6" % (S_STAMP, S_STAMP + 1))
+    e.add("s_sub_u32 s%d, s%d, 24" % (S_STAMP0, S_STAMP))
+    e.add("s_subb_u32 s%d, s%d, 0" % (S_STAMP0 + 1, S_STAMP + 1))
     e.add("s_mov_b64 s[%d:%d], %%1" % (S_RSRC, S_RSRC + 1))
     e.add("s_and_b32 s%d, s%d, 0xffff" % (S_RSRC + 1, S_RSRC + 1))
     e.add("s_mov_b32 s%d, %%2" % (S_RSRC + 2))
@@ -480,26 +696,46 @@ def sec_pro(stamps):
     return e
 
 
+# Two schedules of the layer boundary were built and measured:
+#   "skew"        taps 1..8 regular, then the epilogue under tap 0 of the next layer (Emitter.skew)            <- the product
+#   "transition"  taps 1..7 regular, then tap 8 in two halves by output channel with the drains of pairs 0, 1 under the
+#                 second half, drains 2, 3 under the next layer's first groups (Emitter.transition): more fragment loads,
+#                 same wall time
+SCHEDULE = os.environ.get("XQ_1WA_SCHEDULE", "skew")
+
+
 def sec_even(stamps, blk):
     e = Emitter(stamps)
     L = 2 * blk
-    e.comment("---- first convolution of the block: taps 1..8")
     e.add("s_waitcnt lgkmcnt(0)", "lgkm0")                 # the loop head: one known state of the LDS queue for both ways in
-    for tap in range(1, 9):
-        e.tap_regular(L, 0, tap, False, tap < 8)
-    e.stamp(0)
-    # its epilogue (with the block input x for the skip connection) under tap 0 of the second convolution; the bias row of
-    # the next block's first convolution is fetched here (none behind the last block)
-    e.skew(L, L + 1, 18, True, 0, 1, L + 2, True, 1)
+    if SCHEDULE == "skew":
+        e.comment("---- first convolution of the block: taps 1..8")
+        for tap in range(1, 9):
+            e.tap_regular(L, 0, tap, False, tap < 8)
+        e.stamp(0)
+        # its epilogue (with the block input x for the skip connection) under tap 0 of the second convolution; the bias row of
+        # the next block's first convolution is fetched here (none behind the last block)
+        e.skew(L, L + 1, 18, True, 0, 1, L + 2, True, 1)
+    else:
+        e.comment("---- first convolution of the block: taps 1..7")
+        for tap in range(1, 8):
+            e.tap_regular(L, 0, tap, False, True)
+        e.stamp(0)
+        e.transition(L, L + 1, 0, 18, True, 0, 1, L + 2, True, 1, fine=40 if stamps else None)
     return e
 
 
 def sec_odd(stamps, blk):
     e = Emitter(stamps)
     L = 2 * blk + 1
-    e.comment("---- second convolution of the block: taps 1..8")
-    for tap in range(1, 9):
-        e.tap_regular(L, 18, tap, False, tap < 8, clamp_from=36)
+    if SCHEDULE == "skew":
+        e.comment("---- second convolution of the block: taps 1..8")
+        for tap in range(1, 9):
+            e.tap_regular(L, 18, tap, False, tap < 8, clamp_from=36)
+    else:
+        e.comment("---- second convolution of the block: taps 1..7")
+        for tap in range(1, 8):
+            e.tap_regular(L, 18, tap, False, True, clamp_from=36)
     e.stamp(2)
     return e
 
@@ -507,37 +743,62 @@ def sec_odd(stamps, blk):
 def sec_x2(stamps, blk):
     e = Emitter(stamps)
     L = 2 * blk + 1
-    e.skew(L, L + 1, 36, False, 1, 0, L + 2, False, 3)
+    if SCHEDULE == "skew":
+        e.skew(L, L + 1, 36, False, 1, 0, L + 2, False, 3)
+    else:
+        e.transition(L, L + 1, 18, 36, False, 1, 0, L + 2, False, 3, fine=45 if stamps else None)
     return e
 
 
 def sec_fin(stamps, blk):
     e = Emitter(stamps)
-    e.final_drain(2 * blk + 1, 3)
+    L = 2 * blk + 1
+    if SCHEDULE == "skew":
+        e.final_drain(L, 3)
+    else:
+        e.transition(L, None, 18, None, False, 1, 0, None, False, 3, final=True)
     return e
 
 
+LGKM_WINDOW = 8       # an s_waitcnt costs an issue slot even when it does not stall: one wait covers the MFMAs of this window
+
+
 def insert_lgkm_waits(linear):
-    """exact s_waitcnt lgkmcnt(n) in front of every instruction that consumes the result of an LDS read still in flight.
-    LDS operations of a wave complete in order; n = operations issued behind the one waited for.  Returns the new list;
-    sections flagged 'lgkm0' reset the queue (they wait for everything)."""
+    """exact s_waitcnt lgkmcnt(n) in front of every MFMA that consumes the result of an LDS read still in flight.
+    LDS operations of a wave complete in order; n = operations issued behind the one waited for.  A wait also covers the
+    operands of the next LGKM_WINDOW MFMAs as far as their loads have been issued already (they were issued about as long
+    ago as this one's: waiting for them here costs nothing and saves the later waits).  Returns the new list; 'lgkm0'
+    instructions wait for everything."""
     out = []
     nl = 0                    # LDS / SMEM operations issued
     retired = 0               # operations known complete: the first `retired` ones
     pend = {}                 # register key -> index of the read that will write it
-    def need(keys):
-        nonlocal retired
-        k = max([pend[x] for x in keys if x in pend and pend[x] >= retired], default=None)
-        if k is None:
-            return
-        n = min(nl - 1 - k, 15)
-        out.append(Ins("s_waitcnt lgkmcnt(%d)" % n, "lgkmwait", n=n))
-        retired = max(retired, nl - n)
-    for ins in linear:
+
+    def keys_of(ins):
+        return [("f", ins.m["a"]), ("f", ins.m["b"]), ("bias", ins.m["tile"] // 6) if ins.m.get("first") else ("acc", ins.m["tile"])]
+
+    for pos, ins in enumerate(linear):
         k = ins.kind
         if k == "mfma":
-            keys = [("f", ins.m["a"]), ("f", ins.m["b"]), ("bias", ins.m["tile"] // 6) if ins.m.get("first") else ("acc", ins.m["tile"])]
-            need(keys)
+            mine = max([pend[x] for x in keys_of(ins) if x in pend and pend[x] >= retired], default=None)
+            if mine is not None:
+                want = mine
+                seen = 0
+                for nxt in linear[pos + 1:]:
+                    if nxt.kind in ("barrier", "label", "lgkm0", "blk"):
+                        break
+                    if nxt.kind == "mfma":
+                        seen += 1
+                        if seen > LGKM_WINDOW:
+                            break
+                        # operands whose loads are already in the queue (a load emitted between here and there re-defines the
+                        # register: then the register's pending index changes and this look-ahead must not count the old one)
+                        for x in keys_of(nxt):
+                            if x in pend and retired <= pend[x] < nl and not redefined(linear, pos, nxt, x):
+                                want = max(want, pend[x])
+                n = min(nl - 1 - want, 15)
+                out.append(Ins("s_waitcnt lgkmcnt(%d)" % n, "lgkmwait", n=n))
+                retired = max(retired, nl - n)
         elif k == "lgkm0":
             retired = nl
         elif k == "smem":
@@ -554,16 +815,50 @@ def insert_lgkm_waits(linear):
     return out
 
 
+def redefined(linear, pos, upto, key):
+    """is register `key` loaded again between linear[pos] and the instruction object `upto`?"""
+    for x in linear[pos + 1:]:
+        if x is upto:
+            return False
+        if x.kind == "ldsr":
+            d = x.m["dst"]
+            k2 = ("acc", int(d[3:])) if isinstance(d, str) and d.startswith("acc") else (
+                ("bias", int(d[4:])) if isinstance(d, str) and d.startswith("bias") else ("f", d))
+            if k2 == key:
+                return True
+    return False
+
+
 class CheckError(Exception):
     pass
 
 
-def check_and_fill(linear, nblocks):
+def check_and_fill(linear, nblocks, verify=True):
     """symbolic run of the linearized program (one wave's view; every wave runs the same stream, wave 1 also fetches the
     bias rows).  Fills in the vmcnt of every stage barrier.  Raises CheckError on the first violation."""
     def fail(i, msg):
         ctx = "\n".join("   %s%s" % (">> " if j == i else "   ", linear[j].text) for j in range(max(0, i - 6), min(len(linear), i + 3)))
         raise CheckError("instruction %d: %s\n%s" % (i, msg, ctx))
+
+    if not verify:
+        # ablation bodies: only the vmcnt of the barriers is filled in (from the unablated DMA bookkeeping)
+        vq = []
+        blk = 0
+        for ins in linear:
+            if ins.kind == "blk":
+                blk = ins.m["blk"]
+            elif ins.kind == "dma":
+                vq.append(36 * blk + ins.m["lstage"])
+            elif ins.kind == "gstore":
+                vq.append(-1)
+            elif ins.kind == "vmwait":
+                X = ins.m["landed"]
+                idx = -1 if X is not None else len(vq) - 1
+                if X is not None:
+                    idx = max([j for j, x in enumerate(vq) if 0 <= x <= 36 * blk + X], default=-1)
+                ins.m["n"] = min(len(vq) - 1 - idx, 63)
+                ins.text = "s_waitcnt vmcnt(%d)" % ins.m["n"]
+        return True
 
     nlayers = 2 * nblocks
     # LDS activation rows: content[J][n] = layer whose output is stored there (-1 = the input convolution's)
@@ -807,7 +1102,7 @@ def build(stamps, nblocks_check=3):
         linear += [Ins("", "blk", blk=b)] + even[b].ins + odd[b].ins
         linear += x2[b].ins if b < nblocks_check - 1 else fin.ins
     linear = insert_lgkm_waits(linear)
-    check_and_fill(linear, nblocks_check)
+    check_and_fill(linear, nblocks_check, verify=not ABL)
     # split the linear list back into sections by identity of the first / last instruction objects
     def section(first, last):
         i0 = next(i for i, x in enumerate(linear) if x is first)
@@ -826,13 +1121,22 @@ def build(stamps, nblocks_check=3):
     def texts(sec):
         import re
         return [re.sub(r"XQ1WA_\d+_", "XQ1WA_N_", x.text) for x in sec if x.kind != "comment"]
-    for b in range(1, nblocks_check):
-        for name in ("even", "odd"):
-            if texts(S[name + "0"]) != texts(S["%s%d" % (name, b)]):
-                raise CheckError("%s section differs between blocks 0 and %d" % (name, b))
-    for b in range(1, nblocks_check - 1):
-        if texts(S["x2_0"]) != texts(S["x2_%d" % b]):
-            raise CheckError("x2 section differs between blocks")
+    def unify(names):
+        """the block instances of a section may differ in a barrier's vmcnt only (stamped bodies: the stamp stores of the code in
+        front of the loop head differ between the first and the later ways in): the emitted one takes the smallest count - a
+        stricter wait is always valid"""
+        secs = [[x for x in S[nm] if x.kind != "comment"] for nm in names]
+        if any(len(sec) != len(secs[0]) for sec in secs):
+            raise CheckError("section %s: instances differ in length" % names[0])
+        for row in zip(*secs):
+            tx = [texts([x])[0] for x in row]
+            if len(set(tx)) > 1:
+                if not all(x.kind == "vmwait" for x in row):
+                    raise CheckError("section %s differs between blocks: %s" % (names[0], tx))
+                row[0].text = "s_waitcnt vmcnt(%d)" % min(x.m["n"] for x in row)
+    unify(["even%d" % b for b in range(nblocks_check)])
+    unify(["odd%d" % b for b in range(nblocks_check)])
+    unify(["x2_%d" % b for b in range(nblocks_check - 1)])
     return head, S, linear
 
 
@@ -891,11 +1195,29 @@ def generate():
     return "".join(parts), allstats
 
 
+ABLATIONS = [("noaccread",), ("nostore",), ("nodrain",), ("nodma",), ("nobar",), ("nodrain", "nodma", "nobar")]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--check", action="store_true", help="regenerate in memory and compare with the committed file")
     ap.add_argument("--dump", default="", help="write the plain assembly text of the unstamped body to this file")
+    ap.add_argument("--ablations", action="store_true",
+                    help="write csrc/xq_tower1wa_abl.inc: stamped timing-only bodies (wrong results) for a -DXQ_TOWER_PROBES=1 library")
     args = ap.parse_args()
+    if args.ablations:
+        parts = ["// xq_tower1wa_abl.inc - GENERATED by tools/gen_tower1wa.py --ablations: timing-only bodies, wrong results (probes builds only)\n"]
+        for k, flags in enumerate(ABLATIONS, 1):
+            ABL.clear()
+            ABL.update(flags)
+            lines, _ = render(True)
+            parts.append("// ablation %d: %s\n" % (k, ", ".join(flags)))
+            parts.append(as_c_string(lines, "XQ_1WA_BODY_ABL%d" % k))
+        ABL.clear()
+        parts.append("#define XQ_1WA_N_ABL %d\n" % len(ABLATIONS))
+        open(OUT.replace("_body.inc", "_abl.inc"), "w").write("".join(parts))
+        print("wrote", OUT.replace("_body.inc", "_abl.inc"))
+        return 0
     text, stats = generate()
     if args.dump:
         lines, _ = render(False)

@@ -43,7 +43,10 @@ def timeit(fn, it=20):
 
 nwg = (G + 3) // 4
 stamps = torch.zeros(((G + 1) // 2) * 64, dtype=torch.int64, device="cuda")
-for variant in (60, 39):
+ABL_NAMES = {61: "drains read VGPRs, not accumulators", 62: "no stores", 63: "no drain", 64: "no weight DMA", 65: "no barriers",
+             66: "no drain, DMA, barriers"}
+extra = [int(v) for v in os.environ.get("XQ_1WA_ABL", "").split(",") if v]
+for variant in [60] + extra + [39]:
     L.xq_tower_set_variant(variant)
     if L.xq_tower_debug_stamps(*args, stamps.data_ptr()) != 0:
         print("variant %d: no stamped build" % variant)
@@ -56,7 +59,9 @@ for variant in (60, 39):
     print("variant %d stamped: %.3f ms; workgroup %d cycles (median), clock %.3f GHz, workgroup wall %.1f us, launch wall %.1f us" % (
         variant, ms, np.median(tot), np.median(tot / rt * 0.1), np.median(rt) / 100.0, (s[:, 63].max() - s[:, 62].min()) / 100.0))
     d = lambda a, b: int(np.median(s[:, a] - s[:, b]))
-    if variant == 60:
+    if variant in ABL_NAMES:
+        print("  (timing-only body: %s)" % ABL_NAMES[variant])
+    if variant >= 60:
         print("  input conv %d, its epilogue + first DMA %d" % (d(1, 0), d(2, 1)))
         prev = 2
         for b in range(blocks):
@@ -65,6 +70,12 @@ for variant in (60, 39):
                 b, d(k, prev), d(k + 1, k), d(k + 2, k + 1), "epilogue under tap 0" if b < blocks - 1 else "last epilogue", d(k + 3, k + 2)))
             prev = k + 3
         print("  behind the body %d, heads %d, stores %d" % (d(59, prev), d(60, 59), d(61, 60)))
+        if s[:, 40].max() > 0 and blocks >= 2:
+            kx1, kx2 = 3 + 4 * (blocks - 1), 3 + 4 * (blocks - 2) + 2
+            print("  inside the last block's first transition (tap 8 half 1 | half 2 + drains 0, 1 | groups + drain 2 | groups + drain 3 | rest): %d | %d | %d | %d | %d" % (
+                d(40, kx1), d(41, 40), d(42, 41), d(43, 42), d(kx1 + 1, 43)))
+            print("  inside the last-but-one block's second transition: %d | %d | %d | %d | %d" % (
+                d(45, kx2), d(46, 45), d(47, 46), d(48, 47), d(kx2 + 1, 48)))
     else:
         nl = 2 * blocks
         print("  input conv %d + %d | main loops %s | epilogues %s | heads %d + %d" % (
