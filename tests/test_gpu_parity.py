@@ -565,8 +565,9 @@ def test_single_launch_trunk_equals_per_layer_kernels(L):
     from chinesechessai_amd.neural_network import ChessNet, InferenceNet
     from chinesechessai_amd import _lib
     st = torch.cuda.current_stream().cuda_stream
-    # the builds of the trunk kernel: -1 = the library's own choice (k_tower16b with 4 boards per workgroup from 2,048
-    # boards up, 2 below), 36 / 39 = k_tower16b with 2 / 4 boards per workgroup (v_mfma_f32_16x16x32_bf16, output
+    # the builds of the trunk kernel: -1 = the library's own choice (round 4: k_tower1wa - one wave per SIMD, the residual
+    # tower as one hand-written asm statement - from 2,048 boards up, k_tower16b with 2 boards per workgroup below), 60 =
+    # k_tower1wa at any size, 36 / 39 = k_tower16b with 2 / 4 boards per workgroup (v_mfma_f32_16x16x32_bf16, output
     # channels dealt to the MFMA rows 8 per lane, 16-byte epilogue stores, one read / DMA piece per MFMA gap), 0 =
     # k_tower (32x32x16, the comparison build); only the last accumulates in the per-layer kernels' order
     # (bit-identical without residual blocks).  The smallest net on a cold device comes first: that is where a missing
@@ -574,6 +575,7 @@ def test_single_launch_trunk_equals_per_layer_kernels(L):
     same_bits = {}
     for variant, blocks, G in ((36, 1, 2), (36, 6, 37), (36, 2, 129), (36, 0, 5), (36, 6, 1), (36, 3, 64), (36, 20, 3), (36, 1, 1024),
                                (39, 1, 2), (39, 6, 37), (39, 2, 129), (39, 0, 5), (39, 6, 1), (39, 3, 64), (39, 20, 3), (39, 1, 1022),
+                               (60, 1, 2), (60, 6, 37), (60, 2, 129), (60, 0, 5), (60, 6, 1), (60, 3, 64), (60, 20, 3), (60, 1, 1022),
                                (-1, 1, 2), (-1, 6, 37), (-1, 1, 2049), (-1, 2, 2050),
                                (0, 6, 37), (0, 0, 5), (0, 2, 3)):
         L.xq_tower_set_variant(variant)
@@ -600,7 +602,7 @@ def test_single_launch_trunk_equals_per_layer_kernels(L):
         torch.cuda.synchronize()
         assert P0.abs().max().item() > 0
         assert (P1[G] == 9.0).all() and (V1[G] == 9.0).all()
-        if variant in (36, 39, -1):                          # one accumulation order: these builds agree to the bit
+        if variant in (36, 39, 60, -1):                      # one accumulation order: these builds agree to the bit
             ref = same_bits.setdefault((blocks, G), (P1[:G].clone(), V1[:G].clone(), variant))
             assert torch.equal(ref[0].view(torch.int16), P1[:G].view(torch.int16)), (variant, ref[2], blocks, G)
             assert torch.equal(ref[1].view(torch.int16), V1[:G].view(torch.int16)), (variant, ref[2], blocks, G)
