@@ -26,7 +26,7 @@ network rows); `value_no_carry` (every root evaluated afresh, as the reference d
 `value_full_policy_head` (all 8,100 policy columns) are measured beside it on a few extra steps.
 
 Prints ONE JSON line (rank 0).  `roofline` = the dominant kernel of the step, the hand-written
-single-launch trunk k_tower16b (csrc/xq_tower.hip; MFMA-bound, ~90 % of GPU time), over its full-size
+single-launch trunk k_tower1wa (csrc/xq_tower1wa.hpp; MFMA-bound, ~80 % of the step), over its full-size
 launches (rows = games; the carried-over rounds launch it with zero rows and are listed apart); `roofline_net` =
 the whole network forward over all launches and the rows they really evaluated; `roofline_tree` = the tree/rules
 kernel k_search_round (HBM-bound integer work); all measured live with events on the stream the kernels run on.
@@ -74,7 +74,7 @@ def pmc_traffic(kernel, G, S, blocks, fetch_factor=1.0):
     correction, MI355X_MICROARCH.md); (None, None) for configs that were not profiled."""
     if not (G == 16384 and S == 50 and blocks == 6):
         return None, None
-    for name in ("r03_pmc_kernels.json", "r02c_pmc_kernels.json", "r02b_pmc_kernels.json", "r02_pmc_kernels.json", "r01g_pmc_kernels.json", "r01f_pmc_kernels.json", "r01d_pmc_kernels.json"):
+    for name in ("r04_pmc_kernels.json", "r03_pmc_kernels.json", "r02c_pmc_kernels.json", "r02b_pmc_kernels.json", "r02_pmc_kernels.json", "r01g_pmc_kernels.json", "r01f_pmc_kernels.json", "r01d_pmc_kernels.json"):
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
             doc = json.load(open(path))
@@ -364,11 +364,15 @@ def run_rank(args):
     net = ChessNet(num_blocks=args.blocks).eval().cuda()
     bcast_bytes = xd.broadcast_weights(net, src=0) if use_dist else 0
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    weights_equal = None
 
     def make_ev(policy_columns, leaf_dedupe=True):
         return TorchNetEvaluator(net, dtype=dtype, chunk=args.net_chunk or None, policy_columns=policy_columns,
                                  fused_tower=bool(args.fused_tower), leaf_dedupe=leaf_dedupe)
     ev = make_ev(args.policy_columns, not args.no_leaf_dedupe)
+    if use_dist:
+        # every rank's leaf evaluator reads the same bits: MIN / MAX all-reduce of a digest of the folded weights
+        weights_equal = xd.weights_equal_across_ranks(ev.inet.folded_weights())
     stream = torch.cuda.current_stream().cuda_stream
     records = torch.zeros((args.refill if args.refill else G) * _lib.MAX_PLIES * xd.RECORD_BYTES, dtype=torch.uint8, device="cuda")
     pipe = xd.RecordGather(records.numel(), "cuda") if use_dist else None
@@ -453,12 +457,19 @@ def run_rank(args):
     eng.row_history(cap=0, reset=True)
     eng.profile(True)
     tm.on(True)
+    # shader clock held while the trunk kernel runs: one workgroup in 64 adds its cycles / 100 MHz ticks (xq_debug.h)
+    clock_buf = torch.zeros(3, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    _lib.lib().xq_tower_set_clock_sample(clock_buf.data_ptr())
     t0 = time.time()
     for k in range(args.steps):
         step(eng, ev, k * TG * world)
     sync()
     dt = time.time() - t0
     tm.on(False)
+    _lib.lib().xq_tower_set_clock_sample(None)
+    clk = clock_buf.cpu().numpy()
+    trunk_clock_ghz = float(clk[0]) / float(clk[1]) * 0.1 if clk[1] > 0 else None
     prof = eng.profile_read()
     carry_on = eng._carry_on
     rows_hist, n_rounds = eng.row_history(reset=True) if eng.row_compaction else (None, 0)
@@ -509,13 +520,28 @@ def run_rank(args):
         fl = net_flops_per_row(args.blocks)
         fl -= 2 * 2880 * (8100 - ev.inet.n_policy_real)        # only the policy columns actually computed count (no padding)
         # rows each forward really evaluated (row compaction: device-side counts of every search round, in launch order)
-        if rows_hist is not None and len(rows_hist) == n_fw:
+        rows_known = rows_hist is not None and len(rows_hist) == n_fw
+        if rows_known:
             rows_fw = rows_hist.astype(np.int64)
         else:
+            # no row compaction (every launch runs every slot), or more search rounds than the engine's row history keeps
+            # (65,536): then the row-derived figures below are upper bounds and say so
             rows_fw = np.full(n_fw, rows, np.int64)
+        rows_note = None if (rows_known or not eng.row_compaction) else (
+            "row history incomplete (%d rounds launched, the engine keeps %d): rows_evaluated / roofline_net / "
+            "end_to_end_mfma_frac assume full-size launches and are upper bounds" % (n_rounds, len(rows_hist)))
         net_tflops = float(fl * rows_fw.sum()) / (fw_ms * 1e-3) / 1e12 if fw_ms > 0 else 0.0
-        bpd = tree_bytes_per_descent()
-        tree_gbs = (bpd * G * prof["search_launches"]) / (prof["search_ms"] * 1e-3) / 1e9 if prof["search_ms"] > 0 else 0.0
+        # k_search_round, priced by what each launch does: under the carry-over round 0 of every ply after a game's first has
+        # nothing pending and nothing to descend to (the root is expanded, its 8 visits are booked): 64 B per game (board +
+        # scalars); every other launch is a descent (tree_bytes_per_descent) plus, with the leaf dedupe, the 13 words of the
+        # position written past the L2 and the table entry (52 + 8 B written, 8 + 52 B read on a probe: 120 B)
+        bpd = tree_bytes_per_descent() + (120.0 if eng.leaf_dedupe else 0.0)
+        n_search = prof["search_launches"]
+        n_light = 0
+        if carry_on and not args.refill and eng.rounds > 0:
+            n_light = max(n_search // eng.rounds - args.steps, 0)          # plies played minus the first ply of every step
+        tree_bytes = (n_search - n_light) * bpd * G + n_light * 64.0 * G
+        tree_gbs = tree_bytes / (prof["search_ms"] * 1e-3) / 1e9 if prof["search_ms"] > 0 else 0.0
         # dominant kernel: the single-launch trunk (or, with --fused-tower 0, the per-layer conv)
         fused = bool(args.fused_tower) and ev.inet.use_hip_conv
         if fused:       # k_tower: conv1 + 2*blocks convs + both heads per launch
@@ -533,8 +559,11 @@ def run_rank(args):
                         "empty": int((rows_tw == 0).sum()), "partial": int(((rows_tw > 0) & ~full).sum()),
                         "empty_ms_avg": float(tw_t[rows_tw == 0].mean()) if (rows_tw == 0).any() else None,
                         "all_launches": int(len(tw_t)), "all_ms": float(tw_t.sum())}
-            kname, kdesc = "k_tower", "k_tower16b<NB = %d>, hand-written single-launch trunk on v_mfma_f32_16x16x32_bf16: conv3x3(16->128) + %d fused residual convs + 1x1 heads, activations resident in LDS, %d boards per workgroup share one weight stream" % (
-                4 if rows >= 2048 else 2, 2 * args.blocks, 4 if rows >= 2048 else 2)
+            tv = args.tower_variant if args.tower_variant >= 0 else (60 if rows >= 2048 else 36)
+            kbuild = {60: "k_tower1wa (one wave per SIMD, 4 boards per workgroup, the residual tower as one hand-written asm statement)",
+                      39: "k_tower16b<NB = 4>", 36: "k_tower16b<NB = 2>", 0: "k_tower (32x32x16)"}.get(tv, "variant %d" % tv)
+            kname, kdesc = "k_tower", "%s, hand-written single-launch trunk on v_mfma_f32_16x16x32_bf16: conv3x3(16->128) + %d fused residual convs + 1x1 heads, activations resident in LDS" % (
+                kbuild, 2 * args.blocks)
         else:
             n_conv = 2 * args.blocks * len(tw_t)
             conv_ms = float(tw_t.sum())
@@ -544,6 +573,17 @@ def run_rank(args):
         conv_tflops = conv_fl * n_conv / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
         tr_tower = pmc_traffic(kname, G, S, args.blocks, fetch_factor=2.0) if rows == G else (None, None)
         tr_tree = pmc_traffic("k_search_round", G, S, args.blocks)
+        tr_fc = pmc_traffic("k_policy_fc", G, S, args.blocks, fetch_factor=2.0) if rows == G else (None, None)
+        # counter traffic over algorithmic HBM bytes per launch (the profiled passes run full-size launches without dedupe):
+        # trunk: planes in + head activations out + the weight set once; tree: a descent per game; policy FC: activations in
+        # + weights + logits out
+        alg_tower = rows * (2880.0 + 7200.0) + (2.0 * (16 * 9 * 128 + 2 * args.blocks * 128 * 9 * 128 + 128 * 64) + 4.0 * 128 * (1 + 2 * args.blocks))
+        alg_fc = rows * 2880.0 * 2 + 2880.0 * ev.inet.n_policy * 2 + rows * ev.inet.n_policy * 2.0
+        ratio = lambda t, a: (t / a) if t else None
+        traffic_ratio = {"k_tower": ratio(tr_tower[0], alg_tower), "k_search_round": ratio(tr_tree[0], tree_bytes_per_descent() * G),
+                         "k_policy_fc": ratio(tr_fc[0], alg_fc),
+                         "note": "HBM bytes from the committed PMC passes (FETCH_SIZE x2 for the 16-byte-per-lane readers + WRITE_SIZE; tree kernel: "
+                                 "FETCH_SIZE + WRITE_SIZE) over algorithmic bytes per full-size launch", "source": tr_tower[1] or tr_tree[1]}
         extras = [", policy FC on the %d columns a legal move can index (of 8,100; the others are never read by the search "
                   "and are not counted as work)" % ev.inet.n_policy_real if args.policy_columns == "reachable"
                   else ", full 8,100-column policy FC"]
@@ -581,23 +621,33 @@ def run_rank(args):
             "config": {"workload": workload,
                        "games_per_gpu": G, "sims": S, "blocks": args.blocks, "max_moves": 70,
                        "parallelism": "games sharded x%d, weights broadcast from rank 0 (%d bytes), all-gather of samples at step end" % (world, bcast_bytes)},
+            "ranks": world, "weights_equal": weights_equal,
             "roofline": {"bound": "mfma", "achieved": conv_tflops, "peak": MFMA_PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": conv_tflops / MFMA_PEAK_BF16_TFLOPS,
                          "traffic": tr_tower[0], "traffic_source": tr_tower[1],
                          "kernel": "%s (%s; %d full-size launches of %d boards on average, %.4f ms avg; %.0f%% of the step)" % (
                              kname, kdesc, n_conv, int(round(conv_fl / (per_board if fused else conv_fl / rows))), conv_ms / max(n_conv, 1),
                              100.0 * conv_ms / (dt * 1e3)),
-                         "flops_per_launch": conv_fl, "launches": launches},
+                         "flops_per_launch": conv_fl, "launches": launches,
+                         "clock_ghz": trunk_clock_ghz,
+                         "clock_note": "shader clock the chip held inside the trunk kernel over the timed region (s_memtime / s_memrealtime "
+                                       "of one workgroup in 64, k_tower1wa only); 2.4 GHz is the peak's clock: frac = MFMA-pipe efficiency x clock / 2.4"},
             "roofline_net": {"bound": "mfma", "achieved": net_tflops, "peak": MFMA_PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                              "frac": net_tflops / MFMA_PEAK_BF16_TFLOPS, "traffic": None,
                              "kernel": "whole network forward (%d launches, %d rows evaluated in all, %.3f ms avg over all launches)" % (
                                  n_fw, int(rows_fw.sum()), fw_ms / max(n_fw, 1)),
-                             "flops_per_row": fl, "rows_evaluated": int(rows_fw.sum())},
+                             "flops_per_row": fl, "rows_evaluated": int(rows_fw.sum()), "note": rows_note},
+            # the whole step against the MFMA peak: every network row evaluated x its flops, over the WALL time of the timed region
+            "end_to_end_mfma_frac": float(fl * rows_fw.sum()) / dt / 1e12 / MFMA_PEAK_BF16_TFLOPS / world,
             "roofline_tree": {"bound": "hbm", "achieved": tree_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": tree_gbs / HBM_PEAK_GBS, "traffic": tr_tree[0], "traffic_source": tr_tree[1],
                               "kernel": "k_search_round (%d launches, %.3f ms avg)" % (
                                   prof["search_launches"], prof["search_ms"] / max(prof["search_launches"], 1)),
-                              "bytes_per_launch": bpd * G},
+                              "bytes_per_launch": tree_bytes / max(n_search, 1),
+                              "bytes_note": "%d launches that descend (%.0f B per game: board + scalars, PUCT reads, leaf moves / board / planes, "
+                                            "logit gather, edge init, backup%s) + %d launches of round 0 under the carry-over (64 B per game)" % (
+                                                n_search - n_light, bpd, ", dedupe words + table entry" if eng.leaf_dedupe else "", n_light)},
+            "traffic_over_algorithmic": traffic_ratio,
             "time_share": {"net_forward_ms": fw_ms, "k_search_round_ms": prof["search_ms"],
                            "k_play_move_ms": prof["play_ms"], "wall_ms": dt * 1e3},
             "games": {"mean_plies": float(outcomes["n_plies"].mean()),

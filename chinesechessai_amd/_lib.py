@@ -186,6 +186,7 @@ _SIGNATURES = {
 # diagnostics (include/xq_debug.h): build selectors, phase stamps, timing probes - tools and build-comparison tests only
 _DEBUG_SIGNATURES = {
     "xq_tower_set_variant": (None, [C.c_int]),
+    "xq_tower_set_clock_sample": (None, [C.c_void_p]),
     "xq_tower_debug_stamps": (C.c_int, [C.c_void_p] * 9 + [C.c_int, C.c_int, C.c_void_p]),
     "xq_mfma_probe": (C.c_int, [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_int]),
     "xq_conv3x3_set_variant": (None, [C.c_int]),

@@ -225,6 +225,11 @@ __global__ __launch_bounds__(256, 1) void k_tower1wa(TowerArgs A)
         }
     };
     stamp(0);
+    // clock sample (xq_tower_set_clock_sample; product build only): one workgroup in 64 adds its shader cycles and its
+    // 100 MHz ticks to three counters; bench.py divides them - the clock the chip held while this kernel ran
+    unsigned long long clk0 = 0, rt0 = 0;
+    const bool clk_sample = !STAMP && A.stamps != nullptr && (blockIdx.x & 63) == 0;
+    if (clk_sample) { clk0 = __builtin_amdgcn_s_memtime(); rt0 = __builtin_amdgcn_s_memrealtime(); }
     XQ_AGPR_ALL();
     f32x4 acc[48];                                                     // stand-ins of the tiles: tile (mt, n) = acc[mt * 6 + n] lives in a[4t : 4t + 3]
     const int tid = threadIdx.x, lane = tid & 63;
@@ -433,6 +438,14 @@ __global__ __launch_bounds__(256, 1) void k_tower1wa(TowerArgs A)
         }
     }
     stamp(61);
+    if (clk_sample) {
+        const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+        if (threadIdx.x == 0) {
+            atomicAdd(A.stamps + 0, c1 - clk0);
+            atomicAdd(A.stamps + 1, r1 - rt0);
+            atomicAdd(A.stamps + 2, 1ull);
+        }
+    }
 }
 
 }  // namespace

@@ -16,11 +16,17 @@ extern "C" {
 #endif
 
 /* Build of the single-launch trunk kernel behind xq_tower_nhwc_bf16 (process-wide): -1 = automatic (the product:
- * 4 boards per workgroup from 2,048 boards up, 2 below), 36 / 39 = k_tower16b with 2 / 4 boards per workgroup,
- * 60 = k_tower1wa (one wave per SIMD, hand-written layer body), 0 = k_tower (32x32x16 comparison build); every other
- * value exists only in a -DXQ_TOWER_PROBES=1 library (experiments, ablations with wrong results).  Builds 36, 39
- * and 60 compute the same bits. */
+ * k_tower1wa from 2,048 boards up, k_tower16b with 2 boards per workgroup below), 36 / 39 = k_tower16b with 2 / 4 boards per workgroup,
+ * 60 = k_tower1wa (one wave per SIMD, hand-written layer body: the product from 2,048 boards up), 0 = k_tower (32x32x16
+ * comparison build); every other value exists only in a -DXQ_TOWER_PROBES=1 library (experiments, ablations with wrong
+ * results).  Builds 36, 39 and 60 compute the same bits. */
 void xq_tower_set_variant(int variant);
+
+/* Clock sample of the trunk kernel (process-wide; NULL = off, the default): while set, one workgroup in 64 of every
+ * k_tower1wa launch through xq_tower_nhwc_bf16 adds its shader cycles (s_memtime), its 100 MHz ticks (s_memrealtime) and 1
+ * to dev_u64x3[0..2] (device memory, zeroed by the caller).  cycles / ticks * 0.1 = the shader clock in GHz the chip held
+ * while the kernel ran (MI355X_MICROARCH.md "DVFS give-back" item 6).  Results do not change. */
+void xq_tower_set_clock_sample(void *dev_u64x3);
 
 /* xq_tower_nhwc_bf16 with s_memtime phase stamps: 64 uint64 per workgroup into stamps_dev (0 start, 1 input conv
  * done, 2 its epilogue, 3+2L / 4+2L main loop / epilogue of layer L, 60 heads' MFMAs done, 61 end, 62 / 63

@@ -1,4 +1,4 @@
-"""Summarise rocprofv3 --pmc passes into profiles/<name>.json (KB per launch, per kernel).
+"""Summarise rocprofv3 --pmc passes into profiles/<name>.json (per kernel: mean per launch; FETCH_SIZE / WRITE_SIZE in KB).
 
 usage: python tools/pmc_summary.py OUT.json DIR_FETCH DIR_WRITE [note]
 Each DIR is the -d output of one `rocprofv3 --pmc <COUNTER> --kernel-trace --output-format csv`
@@ -43,7 +43,9 @@ def main():
     for d in dirs:
         for (kname, counter), (total, ids) in read(d).items():
             e = kernels.setdefault(kname, {})
-            e["%s_KB_mean_per_launch" % counter] = total / max(len(ids), 1)
+            # FETCH_SIZE / WRITE_SIZE count kilobytes; every other counter (SQ_*) is a plain count
+            unit = "_KB" if counter in ("FETCH_SIZE", "WRITE_SIZE") else ""
+            e["%s%s_mean_per_launch" % (counter, unit)] = total / max(len(ids), 1)
             e["launches_%s" % counter] = len(ids)
     json.dump({"note": note, "kernels": kernels}, open(out, "w"), indent=1)
     for k, v in sorted(kernels.items()):
