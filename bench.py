@@ -350,8 +350,20 @@ def run_rank(args):
     if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
+        # RCCL prints a version banner on stdout when its first communicator comes up: stdout carries the ONE JSON line, so
+        # the banner goes to stderr (file descriptor 1 points at 2 until the first collective has run)
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
+            dist.all_reduce(torch.zeros(1, device="cuda"))
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
     else:
         torch.cuda.set_device(0)
     dev = torch.cuda.current_device()

@@ -845,6 +845,11 @@ static int launch_tower(void *stream, const void *planes, const void *w1, const 
     else if (STAMP && v == 64) XQ_TOWER_LAUNCH((k_tower1wa<true, 4>), grid4, 256, LDS_BYTES1WA);
     else if (STAMP && v == 65) XQ_TOWER_LAUNCH((k_tower1wa<true, 5>), grid4, 256, LDS_BYTES1WA);
     else if (STAMP && v == 66) XQ_TOWER_LAUNCH((k_tower1wa<true, 6>), grid4, 256, LDS_BYTES1WA);
+    else if (STAMP && v == 67) XQ_TOWER_LAUNCH((k_tower1wa<true, 7>), grid4, 256, LDS_BYTES1WA);     // Winograd go / no-go probes: 2, 3, 4 extra VALU
+    else if (STAMP && v == 68) XQ_TOWER_LAUNCH((k_tower1wa<true, 8>), grid4, 256, LDS_BYTES1WA);     //   per MFMA; 3 / 4 with 3.5 x the weight DMA
+    else if (STAMP && v == 69) XQ_TOWER_LAUNCH((k_tower1wa<true, 9>), grid4, 256, LDS_BYTES1WA);
+    else if (STAMP && v == 70) XQ_TOWER_LAUNCH((k_tower1wa<true, 10>), grid4, 256, LDS_BYTES1WA);
+    else if (STAMP && v == 71) XQ_TOWER_LAUNCH((k_tower1wa<true, 11>), grid4, 256, LDS_BYTES1WA);
     else if (STAMP && v == 51) XQ_TOWER_LAUNCH((k_tower1w<true, 1>), grid4, 256, LDS_BYTES1W);       // ... no stage barriers (wrong results)
     else if (STAMP && v == 52) XQ_TOWER_LAUNCH((k_tower1w<true, 3>), grid4, 256, LDS_BYTES1W);       // ... no barriers, no vmcnt waits
     else if (STAMP && v == 53) XQ_TOWER_LAUNCH((k_tower1w<true, 7>), grid4, 256, LDS_BYTES1W);       // ... and no weight DMA

@@ -365,6 +365,11 @@ __global__ __launch_bounds__(256, 1) void k_tower1wa(TowerArgs A)
         else if constexpr (ABL == 4) XQ_1WA_RUN_ABL(4);
         else if constexpr (ABL == 5) XQ_1WA_RUN_ABL(5);
         else if constexpr (ABL == 6) XQ_1WA_RUN_ABL(6);
+        else if constexpr (ABL == 7) XQ_1WA_RUN_ABL(7);
+        else if constexpr (ABL == 8) XQ_1WA_RUN_ABL(8);
+        else if constexpr (ABL == 9) XQ_1WA_RUN_ABL(9);
+        else if constexpr (ABL == 10) XQ_1WA_RUN_ABL(10);
+        else if constexpr (ABL == 11) XQ_1WA_RUN_ABL(11);
         else
 #endif
         if constexpr (STAMP)

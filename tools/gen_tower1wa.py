@@ -118,6 +118,8 @@ class Emitter:
         self.add("; " + s, "comment")
 
     NLABEL = [0]
+    NVALU = [0]
+    NDMA = [0]
 
     def label(self):
         Emitter.NLABEL[0] += 1
@@ -140,6 +142,14 @@ class Emitter:
         c = A_BIAS + 4 * (tile // 6) if first else t
         self.add("v_mfma_f32_16x16x32_bf16 a[%d:%d], %s, %s, a[%d:%d]" % (t, t + 3, reg(a), reg(b), c, c + 3), "mfma",
                  tile=tile, a=a, b=b, want=want, first=first)
+        # Winograd go / no-go probe (timing only): k independent f32 adds behind every MFMA = the lane-local input / output
+        # transforms F(2x2, 3x3) would put beside it
+        for fl in ABL:
+            if fl.startswith("valu"):
+                for k in range(int(fl[4:])):
+                    r = V_RD[0] + (Emitter.NVALU[0] % 24)
+                    Emitter.NVALU[0] += 1
+                    self.add("v_add_f32 v%d, v%d, v%d" % (r, r, V_SEL + (k & 7)), "valu", wr=[r])
 
     def load_a(self, slot, lstage, kk, mt, want):
         """weight fragment mt of local stage lstage, K-step parity kk -> slot"""
@@ -163,6 +173,12 @@ class Emitter:
             self.add("s_min_u32 s%d, s%d, s%d" % (S_T, S_T, S_MAX + j))
         self.add("s_add_u32 m0, s%d, 0x%x" % (S_LDST + j, rs * WBUF))
         self.add("s_nop 0")
+        if "dma35" in ABL:
+            # Winograd probe: the transformed weight set (16 positions, 512 KB per layer) streamed once per 2 boards instead of
+            # 288 KB once per 4: 3.5 x the pieces
+            Emitter.NDMA[0] += 1
+            for _ in range(3 if Emitter.NDMA[0] & 1 else 2):
+                self.add("buffer_load_dwordx4 v%d, s[%d:%d], s%d offen lds" % (V_WSRC + (j & 1), S_RSRC, S_RSRC + 3, S_T), "dma_extra")
         if "nodma" in ABL:
             self.add("s_nop 0", "dma", lstage=lstage, piece=j)
         else:
@@ -1195,7 +1211,8 @@ def generate():
     return "".join(parts), allstats
 
 
-ABLATIONS = [("noaccread",), ("nostore",), ("nodrain",), ("nodma",), ("nobar",), ("nodrain", "nodma", "nobar")]
+ABLATIONS = [("noaccread",), ("nostore",), ("nodrain",), ("nodma",), ("nobar",), ("nodrain", "nodma", "nobar"),
+             ("valu2",), ("valu3",), ("valu4",), ("valu3", "dma35"), ("valu4", "dma35")]
 
 
 def main():
