@@ -221,7 +221,7 @@ class Emitter:
         self.add("s_mov_b64 exec, -1")
 
     # ---- one regular tap: 4 K-steps = 2 weight stages ------------------------------------------------------------------------
-    def tap_regular(self, lt, lbase, tap, first_load, prefetch_next, clamp_from=None):
+    def tap_regular(self, lt, lbase, tap, first_load, prefetch_next, clamp_from=None, ks_stop=4):
         """K-steps (tap, 0..3) of the layer tagged lt (first local stage lbase) in k_tower1w's issue order: per pixel tile n
         8 MFMAs with one filler per MFMA gap - the next K-step's activation fragment of tile n, one or two of its weight
         fragments, a DMA piece.  first_load: nothing prefetched this tap's first K-step; prefetch_next: the last K-step
@@ -231,7 +231,7 @@ class Emitter:
                 self.load_a(mt, lbase + 2 * tap, 0, mt, (lt, tap, 0, mt))
             for n in range(6):
                 self.load_b(8 + n, tap, 0, n, (lt, tap, 0, n))
-        for ks in range(4):
+        for ks in range(ks_stop):
             cur, nxt = ks & 1, (ks & 1) ^ 1
             sl, kk = ks >> 1, ks & 1
             p = 2 * tap + sl
@@ -332,14 +332,46 @@ class Emitter:
             else:
                 self.add("ds_write_b128 v%d, v[%d:%d]" % (a, V_PK[st], V_PK[st] + 3), "ldsw", store=(lt, J, n), data=V_PK[st])
         elif kind == "biasrow":
-            _, mt, bslot = op
+            mt, bslot = op[1], op[2]
             self.add("ds_read_b128 a[%d:%d], v%d offset:%d" % (A_BIAS + 4 * mt, A_BIAS + 4 * mt + 3, V_LBQ, bslot * 512 + (mt >> 1) * 128 + (mt & 1) * 16),
                      "ldsr", dst="bias%d" % mt, src=("bias", bslot), want=("BIASROW", lt_next, mt))
         else:
             raise ValueError(kind)
 
     # ---- epilogue of layer lt under tap 0 of the next layer -------------------------------------------------------------------
-    def skew(self, lt, lt_next, lbase_next, rx, bias_slot, bias_fetch_slot, bias_fetch_tag, bias_skip_last, stamp_k):
+    def last_kstep(self, lt, lbase, pair_major, fillers):
+        """K-step (tap 8, ks 3) of layer lt from buffer 1 (tap_regular(tap 8, ks_stop=3) prefetched it).  Regular order carries
+        the stage's DMA pieces like every second K-step of a stage; pair_major: output pair by output pair, so that pair 0
+        is complete after 12 MFMAs and `fillers` (the bias row loads, the head of its drain) issue under pairs 2 and 3.
+        Returns the fillers it did not place."""
+        tap, ks, p = 8, 3, 17
+        fillers = list(fillers)
+        if not pair_major:
+            for n in range(6):
+                for mt in range(8):
+                    self.mfma(TILE(mt, n), 14 + mt, 14 + 8 + n, (lt, tap, ks))
+            return fillers
+        dma = [(lbase + p + 3, j) for j in range(4)]
+        k = 0
+        for P in range(4):
+            for n in range(6):
+                for o in range(2):
+                    self.mfma(TILE(2 * P + o, n), 14 + 2 * P + o, 14 + 8 + n, (lt, tap, ks))
+                    k += 1
+                    if k == 4:
+                        self.barrier(lbase + p + 1, "B%d" % p)          # (the place it has in the regular order: behind the first MFMAs)
+                    elif 4 < k <= 20 and k % 4 == 0 and dma:
+                        ls, j = dma.pop(0)
+                        self.dma_piece(ls, j)
+                    elif k > 24:
+                        for _ in range(2):
+                            if fillers:
+                                f = fillers.pop(0)
+                                self.emit_op(f, lt, None if f[0] != "biasrow" else f[3])
+        assert not dma
+        return fillers
+
+    def skew(self, lt, lt_next, lbase_next, rx, bias_slot, bias_fetch_slot, bias_fetch_tag, bias_skip_last, stamp_k, lead_in=None):
         """drain of layer lt (pairs 0..3) with tap 0 of layer lt_next (first local stage lbase_next) issued as its operands
         become ready.  MFMA group (P, K) = output pair P x input group K, 12 MFMAs, ready after drain max(P, K); inside a
         pair the input groups ascend, so every accumulator sees (tap 0: ks 0, 1, 2, 3) in order.  Segment J = the groups
@@ -347,6 +379,9 @@ class Emitter:
         Fragment slots: activation fragment (K, n) = slot 6 K + n (resident until its last group), weight fragments of
         group i = slots 24 + 2 (i mod 3)."""
         self.comment("---- epilogue of layer %s under tap 0 of layer %s" % (lt, lt_next))
+        head = [("biasrow", mt, bias_slot, lt_next) for mt in range(8)] + self.drain_ops(0, rx, bias_slot, False)
+        if lead_in is not None:
+            head = self.last_kstep(lt, lead_in, True, head)
         # B_E: every wave has left the main loop (its last stage's slot may be refilled: the DMA of stage 3 follows) and the
         # next layer's stages 0 and 1 have landed
         self.barrier(lbase_next + 1, "BE")
@@ -392,11 +427,9 @@ class Emitter:
             else:
                 self.mfma(m[1], "sel%d" % m[2], "xf%d" % m[3], ("skip", lt_next), first=True)
 
-        # the next layer's bias row into a[A_BIAS ..] (8 loads instead of one per tile: the tiles' first MFMAs take it as C)
-        for mt in range(8):
-            emit_f(("biasrow", mt, bias_slot))
-        # phase A: drain of pair 0 (nothing to put it under)
-        for f in self.drain_ops(0, rx, bias_slot, False):
+        # the next layer's bias row into a[A_BIAS ..] (8 loads instead of one per tile: the tiles' first MFMAs take it as C) and
+        # phase A: the drain of pair 0 - what the layer's last K-step did not take under its MFMAs
+        for f in head:
             emit_f(f)
         dma3 = [("dma", lbase_next + 3, j) for j in range(4)]       # the next layer's stage 3: under the first MFMAs
         for J in range(4):
@@ -649,8 +682,10 @@ class Emitter:
             self.add("s_waitcnt lgkmcnt(0)", "lgkm0")
         self.stamp(stamp_k)
 
-    def final_drain(self, lt, stamp_k):
+    def final_drain(self, lt, stamp_k, lead_in=None):
         self.comment("---- epilogue of the last layer")
+        if lead_in is not None:
+            self.last_kstep(lt, lead_in, False, [])
         self.barrier(None, "BF")
         for J in range(4):
             for op in self.drain_ops(J, False, 0, True):
@@ -725,13 +760,13 @@ def sec_even(stamps, blk):
     L = 2 * blk
     e.add("s_waitcnt lgkmcnt(0)", "lgkm0")                 # the loop head: one known state of the LDS queue for both ways in
     if SCHEDULE == "skew":
-        e.comment("---- first convolution of the block: taps 1..8")
+        e.comment("---- first convolution of the block: taps 1..8 (the last K-step opens the epilogue)")
         for tap in range(1, 9):
-            e.tap_regular(L, 0, tap, False, tap < 8)
+            e.tap_regular(L, 0, tap, False, tap < 8, ks_stop=3 if tap == 8 else 4)
         e.stamp(0)
         # its epilogue (with the block input x for the skip connection) under tap 0 of the second convolution; the bias row of
         # the next block's first convolution is fetched here (none behind the last block)
-        e.skew(L, L + 1, 18, True, 0, 1, L + 2, True, 1)
+        e.skew(L, L + 1, 18, True, 0, 1, L + 2, True, 1, lead_in=0)
     else:
         e.comment("---- first convolution of the block: taps 1..7")
         for tap in range(1, 8):
@@ -745,9 +780,9 @@ def sec_odd(stamps, blk):
     e = Emitter(stamps)
     L = 2 * blk + 1
     if SCHEDULE == "skew":
-        e.comment("---- second convolution of the block: taps 1..8")
+        e.comment("---- second convolution of the block: taps 1..8 (the last K-step opens the epilogue)")
         for tap in range(1, 9):
-            e.tap_regular(L, 18, tap, False, tap < 8, clamp_from=36)
+            e.tap_regular(L, 18, tap, False, tap < 8, clamp_from=36, ks_stop=3 if tap == 8 else 4)
     else:
         e.comment("---- second convolution of the block: taps 1..7")
         for tap in range(1, 8):
@@ -760,7 +795,7 @@ def sec_x2(stamps, blk):
     e = Emitter(stamps)
     L = 2 * blk + 1
     if SCHEDULE == "skew":
-        e.skew(L, L + 1, 36, False, 1, 0, L + 2, False, 3)
+        e.skew(L, L + 1, 36, False, 1, 0, L + 2, False, 3, lead_in=18)
     else:
         e.transition(L, L + 1, 18, 36, False, 1, 0, L + 2, False, 3, fine=45 if stamps else None)
     return e
@@ -770,7 +805,7 @@ def sec_fin(stamps, blk):
     e = Emitter(stamps)
     L = 2 * blk + 1
     if SCHEDULE == "skew":
-        e.final_drain(L, 3)
+        e.final_drain(L, 3, lead_in=18)
     else:
         e.transition(L, None, 18, None, False, 1, 0, None, False, 3, final=True)
     return e
