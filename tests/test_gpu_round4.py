@@ -268,3 +268,34 @@ def test_row_history_is_clamped_to_what_the_engine_keeps(L):
     assert n == 4 and len(rows) == 4 and rows[0] >= 1
     eng.close()
     assert _lib.ROW_HISTORY == 65536
+
+
+def test_north_star_names_and_the_fp32_notice(L):
+    """BASELINE north_star's names for the surface (`ChessEnv`, `SelfPlay.play_game()`; SURVEY.md section 0 calls them optional)
+    are aliases of the reference's own (chess_env.py:9, self_play.py:178): same game for the same NumPy seed; and the mirror
+    API says once when `inference_dtype='f32'` sends it to PyTorch's library kernels."""
+    import warnings
+    import torch
+    import chinesechessai_amd as xq
+    from chinesechessai_amd import self_play as sp
+    from chinesechessai_amd.engine import HashNetEvaluator
+    assert xq.ChessEnv is xq.ChineseChess
+    env = xq.ChessEnv()
+    assert len(env.get_legal_moves()) == 44
+    np.random.seed(5)
+    a = xq.self_play_game(HashNetEvaluator(), temperature=1.0, num_simulations=16)
+    np.random.seed(5)
+    b = xq.SelfPlay(HashNetEvaluator(), temperature=1.0, num_simulations=16).play_game()
+    assert a[1:] == b[1:] and len(a[0]) == len(b[0])
+    for (ba, pa, za), (bb, pb, zb) in zip(a[0], b[0]):
+        assert np.array_equal(ba, bb) and pa == pb and za == zb
+    torch.manual_seed(1)
+    net = xq.ChessNet(num_blocks=1).eval().cuda()
+    sp._warned_f32 = False
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        r = xq.SelfPlay(net, num_simulations=16).play_games(2, seeds=np.array([1, 2], np.uint32), inference_dtype="f32")
+        r2 = xq.parallel_self_play(net, 2, num_simulations=16, seeds=np.array([1, 2], np.uint32), inference_dtype="f32")
+    assert len(r) == 2 and len(r2) == 2
+    notices = [x for x in w if issubclass(x.category, RuntimeWarning) and "library kernels" in str(x.message)]
+    assert len(notices) == 1                                   # said once, not per call
