@@ -59,6 +59,7 @@ V_LBQ = 175                        # BIAS + (lane >> 4) * 32
 V_SEL = 176                        # skip-connection selectors, two fragments
 V_WSRC = 184                       # weight DMA source offset of this lane: even / odd pieces
 V_L16 = 186                        # lane * 16 (bias DMA source offset)
+V_WSRC4 = (184, 185, 187, 245)     # weight DMA source offset of piece j of this wave: V_WSRC[j & 1] + the piece's offset in a stage (set up in the head)
 TAB_DWORDS = 76
 V_XT = 188                         # 6 address temporaries
 V_RD = (194, 202)                  # 2 x 8 accumulator read-outs
@@ -78,7 +79,9 @@ S_MAX = 53                         # [4] source offset of piece j of the LAST st
 S_CNT = 57                         # blocks left (this one included)
 S_BIASP = 58                       # s[58:59] global address of the next bias row to fetch
 S_WAVE = 60
-S_T = 61                           # temporaries s61, s62, s63
+S_T = 61                           # temporaries s61, s62
+S_STG = 63                         # source offset of the stage whose pieces are being issued
+S_MAXB = 53                        # source offset of the LAST stage (clamp; = S_MAX[0] without the piece offset)
 S_TIME = 64                        # s[64:65] s_memtime
 S_STAMP = 66                       # s[66:67] stamp slot 3 + 4 blk of this workgroup
 S_STAMP0 = 68                      # s[68:69] stamp slot 0 of this workgroup (fine stamps inside a transition)
@@ -166,23 +169,38 @@ class Emitter:
         self.add("ds_read_b128 %s, v%d offset:%d" % (SLOT(slot), src, n * 4096), "ldsr", dst=slot, src=("act", ks, tap, n), want=want)
 
     def dma_piece(self, lstage, j, clamp=False):
+        """1-KB piece j of this wave of local stage lstage -> its ring slot.  Two instructions per piece: the LDS destination
+        into M0 - hoisted in front of the MFMA that precedes the piece, which is the wait state the M0 write needs - and the
+        load; the stage's source offset is computed once per stage (piece 0), the piece's own offset sits in the lane's
+        VGPR offset (V_WSRC4[j])."""
         rs = lstage & 3
         imm = (lstage >> 1) * 32768 + (lstage & 1) * 128
-        self.add("s_add_u32 s%d, s%d, 0x%x" % (S_T, S_PB + j, imm))
-        if clamp:
-            self.add("s_min_u32 s%d, s%d, s%d" % (S_T, S_T, S_MAX + j))
-        self.add("s_add_u32 m0, s%d, 0x%x" % (S_LDST + j, rs * WBUF))
-        self.add("s_nop 0")
+        m0 = Ins("s_add_u32 m0, s%d, 0x%x" % (S_LDST + j, rs * WBUF), "salu")
+        k = len(self.ins) - 1
+        while k >= 0 and self.ins[k].kind != "mfma" and "m0" not in self.ins[k].text and self.ins[k].kind not in ("label", "barrier"):
+            k -= 1
+        hoisted = k >= 0 and self.ins[k].kind == "mfma"
+        if hoisted:
+            self.ins.insert(k, m0)
+        else:
+            self.ins.append(m0)
+        if j == 0:
+            self.add("s_add_u32 s%d, s%d, 0x%x" % (S_STG, S_BLK, imm))
+            if clamp:
+                self.add("s_min_u32 s%d, s%d, s%d" % (S_STG, S_STG, S_MAXB))
+        elif not hoisted:
+            self.add("s_nop 0")
+        S_Tx = S_STG
         if "dma35" in ABL:
             # Winograd probe: the transformed weight set (16 positions, 512 KB per layer) streamed once per 2 boards instead of
             # 288 KB once per 4: 3.5 x the pieces
             Emitter.NDMA[0] += 1
             for _ in range(3 if Emitter.NDMA[0] & 1 else 2):
-                self.add("buffer_load_dwordx4 v%d, s[%d:%d], s%d offen lds" % (V_WSRC + (j & 1), S_RSRC, S_RSRC + 3, S_T), "dma_extra")
+                self.add("buffer_load_dwordx4 v%d, s[%d:%d], s%d offen lds" % (V_WSRC4[j], S_RSRC, S_RSRC + 3, S_STG), "dma_extra")
         if "nodma" in ABL:
             self.add("s_nop 0", "dma", lstage=lstage, piece=j)
         else:
-            self.add("buffer_load_dwordx4 v%d, s[%d:%d], s%d offen lds" % (V_WSRC + (j & 1), S_RSRC, S_RSRC + 3, S_T), "dma", lstage=lstage, piece=j)
+            self.add("buffer_load_dwordx4 v%d, s[%d:%d], s%d offen lds" % (V_WSRC4[j], S_RSRC, S_RSRC + 3, S_STG), "dma", lstage=lstage, piece=j)
 
     def bias_dma(self, slot, lrow, skip_if_last_block=False):
         """wave 1, lanes 0..31: the next bias row -> bias slot `slot` (lrow: tag of the layer whose bias it is)"""
@@ -735,6 +753,12 @@ def sec_head(stamps):
         e.add("s_add_u32 s%d, s%d, s%d" % (S_T, S_T, S_POFF + j))
         e.add("s_sub_u32 s%d, s%d, 0x%x" % (S_MAX + j, S_T, 32768 - 128))
     e.add("s_waitcnt vmcnt(0)", "vm0")
+    # piece j's source offset: the lane's (even / odd piece) + the piece's place in a stage; pieces 2, 3 first (they read
+    # V_WSRC[0 / 1], which pieces 0, 1 then overwrite in place)
+    for j in (2, 3, 0, 1):
+        e.add("v_add_u32 v%d, s%d, v%d" % (V_WSRC4[j], S_POFF + j, V_WSRC + (j & 1)), "valu", wr=[V_WSRC4[j]])
+    e.add("s_mul_i32 s%d, s%d, 0x%x" % (S_MAXB, S_CNT, BLOCK_BYTES))
+    e.add("s_sub_u32 s%d, s%d, 0x%x" % (S_MAXB, S_MAXB, 32768 - 128))
     return e
 
 
