@@ -357,36 +357,50 @@ class Emitter:
             raise ValueError(kind)
 
     # ---- epilogue of layer lt under tap 0 of the next layer -------------------------------------------------------------------
-    def last_kstep(self, lt, lbase, pair_major, fillers):
-        """K-step (tap 8, ks 3) of layer lt from buffer 1 (tap_regular(tap 8, ks_stop=3) prefetched it).  Regular order carries
-        the stage's DMA pieces like every second K-step of a stage; pair_major: output pair by output pair, so that pair 0
-        is complete after 12 MFMAs and `fillers` (the bias row loads, the head of its drain) issue under pairs 2 and 3.
-        Returns the fillers it did not place."""
-        tap, ks, p = 8, 3, 17
+    def last_stage(self, lt, lbase, pair_major, fillers):
+        """The layer's last weight stage = K-steps (tap 8, ks 2) and (tap 8, ks 3).  tap_regular(tap 8, ks_stop=2) left ks 2's
+        fragments in buffer 0; ks 3's go to buffer 1 here (the regular prefetch, moved to the head of the region).
+        pair_major: output pair by output pair - P0: ks 2, ks 3; P1: ks 2, ks 3; ... - every accumulator still sees ks 2 before
+        ks 3, and pair 0 is complete after 24 of the 96 MFMAs, pair 1 after 48, pair 2 after 72: `fillers` (the next layer's bias
+        row loads, drain 0, drain 1 in this order) issue two per MFMA from MFMA 36 on - a drain may start 24 instructions behind
+        its pair's last MFMA - under the MFMAs of the later pairs.  Carries the stage's barrier and DMA pieces like the second
+        K-step of every stage.  Returns the fillers it did not place."""
+        tap, p = 8, 17
         fillers = list(fillers)
-        if not pair_major:
-            for n in range(6):
-                for mt in range(8):
-                    self.mfma(TILE(mt, n), 14 + mt, 14 + 8 + n, (lt, tap, ks))
-            return fillers
+        k3 = [("b", n) for n in range(6)] + [("a", m) for m in range(8)]          # ks 3's loads, in the order of their first use
         dma = [(lbase + p + 3, j) for j in range(4)]
-        k = 0
-        for P in range(4):
-            for n in range(6):
-                for o in range(2):
-                    self.mfma(TILE(2 * P + o, n), 14 + 2 * P + o, 14 + 8 + n, (lt, tap, ks))
-                    k += 1
-                    if k == 4:
-                        self.barrier(lbase + p + 1, "B%d" % p)          # (the place it has in the regular order: behind the first MFMAs)
-                    elif 4 < k <= 20 and k % 4 == 0 and dma:
-                        ls, j = dma.pop(0)
-                        self.dma_piece(ls, j)
-                    elif k > 24:
-                        for _ in range(2):
-                            if fillers:
-                                f = fillers.pop(0)
-                                self.emit_op(f, lt, None if f[0] != "biasrow" else f[3])
-        assert not dma
+        order = []
+        if pair_major:
+            for P in range(4):
+                for ks in (2, 3):
+                    for n in range(6):
+                        for o in range(2):
+                            order.append((ks, 2 * P + o, n))
+        else:
+            for ks in (2, 3):
+                for n in range(6):
+                    for mt in range(8):
+                        order.append((ks, mt, n))
+        for k, (ks, mt, n) in enumerate(order, 1):
+            buf = 14 * (ks & 1)
+            self.mfma(TILE(mt, n), buf + mt, buf + 8 + n, (lt, tap, ks))
+            if k3:
+                kind, i = k3.pop(0)
+                if kind == "b":
+                    self.load_b(14 + 8 + i, tap, 3, i, (lt, tap, 3, i))
+                else:
+                    self.load_a(14 + i, lbase + p, 1, i, (lt, tap, 3, i))
+            if k == 4:
+                self.barrier(lbase + p + 1, "B%d" % p)              # (the place it has in the regular order: behind the first MFMAs)
+            elif 16 <= k <= 28 and k % 4 == 0 and dma:
+                ls, j = dma.pop(0)
+                self.dma_piece(ls, j, clamp=not pair_major)
+            elif pair_major and k > 36:
+                for _ in range(2):
+                    if fillers:
+                        f = fillers.pop(0)
+                        self.emit_op(f, lt, None if f[0] != "biasrow" else f[3])
+        assert not dma and not k3
         return fillers
 
     def skew(self, lt, lt_next, lbase_next, rx, bias_slot, bias_fetch_slot, bias_fetch_tag, bias_skip_last, stamp_k, lead_in=None):
@@ -398,8 +412,13 @@ class Emitter:
         group i = slots 24 + 2 (i mod 3)."""
         self.comment("---- epilogue of layer %s under tap 0 of layer %s" % (lt, lt_next))
         head = [("biasrow", mt, bias_slot, lt_next) for mt in range(8)] + self.drain_ops(0, rx, bias_slot, False)
+        d1 = self.drain_ops(1, rx, bias_slot, False)
         if lead_in is not None:
-            head = self.last_kstep(lt, lead_in, True, head)
+            # the layer's last stage pair-major, with the bias row loads, drain 0 and the head of drain 1 under its MFMAs
+            n0 = len(head)
+            left = self.last_stage(lt, lead_in, True, head + d1)
+            used = n0 + len(d1) - len(left)
+            head, d1 = (head[used:], d1) if used < n0 else ([], d1[used - n0:])
         # B_E: every wave has left the main loop (its last stage's slot may be refilled: the DMA of stage 3 follows) and the
         # next layer's stages 0 and 1 have landed
         self.barrier(lbase_next + 1, "BE")
@@ -462,7 +481,7 @@ class Emitter:
             for f in items[0][2]:
                 emit_f(f)
             if J < 3:
-                low = self.drain_ops(J + 1, rx, bias_slot, False)          # low-priority fillers: the next pair's drain
+                low = d1 if J == 0 else self.drain_ops(J + 1, rx, bias_slot, False)    # low-priority fillers: the next pair's drain
                 if J < 2:                                                  # ... and two pieces of the stage-3 DMA
                     h = len(low) // 3
                     low = low[:h] + [dma3.pop(0)] + low[h:2 * h] + [dma3.pop(0)] + low[2 * h:]
@@ -703,7 +722,7 @@ class Emitter:
     def final_drain(self, lt, stamp_k, lead_in=None):
         self.comment("---- epilogue of the last layer")
         if lead_in is not None:
-            self.last_kstep(lt, lead_in, False, [])
+            self.last_stage(lt, lead_in, False, [])
         self.barrier(None, "BF")
         for J in range(4):
             for op in self.drain_ops(J, False, 0, True):
@@ -784,9 +803,9 @@ def sec_even(stamps, blk):
     L = 2 * blk
     e.add("s_waitcnt lgkmcnt(0)", "lgkm0")                 # the loop head: one known state of the LDS queue for both ways in
     if SCHEDULE == "skew":
-        e.comment("---- first convolution of the block: taps 1..8 (the last K-step opens the epilogue)")
+        e.comment("---- first convolution of the block: taps 1..8 (the last weight stage opens the epilogue)")
         for tap in range(1, 9):
-            e.tap_regular(L, 0, tap, False, tap < 8, ks_stop=3 if tap == 8 else 4)
+            e.tap_regular(L, 0, tap, False, tap < 8, ks_stop=2 if tap == 8 else 4)
         e.stamp(0)
         # its epilogue (with the block input x for the skip connection) under tap 0 of the second convolution; the bias row of
         # the next block's first convolution is fetched here (none behind the last block)
@@ -804,9 +823,9 @@ def sec_odd(stamps, blk):
     e = Emitter(stamps)
     L = 2 * blk + 1
     if SCHEDULE == "skew":
-        e.comment("---- second convolution of the block: taps 1..8 (the last K-step opens the epilogue)")
+        e.comment("---- second convolution of the block: taps 1..8 (the last weight stage opens the epilogue)")
         for tap in range(1, 9):
-            e.tap_regular(L, 18, tap, False, tap < 8, clamp_from=36, ks_stop=3 if tap == 8 else 4)
+            e.tap_regular(L, 18, tap, False, tap < 8, clamp_from=36, ks_stop=2 if tap == 8 else 4)
     else:
         e.comment("---- second convolution of the block: taps 1..7")
         for tap in range(1, 8):
