@@ -403,7 +403,7 @@ class Emitter:
         assert not dma and not k3
         return fillers
 
-    def skew(self, lt, lt_next, lbase_next, rx, bias_slot, bias_fetch_slot, bias_fetch_tag, bias_skip_last, stamp_k, lead_in=None):
+    def skew(self, lt, lt_next, lbase_next, rx, bias_slot, bias_fetch_slot, bias_fetch_tag, bias_skip_last, stamp_k, lead_in=None, fine=None):
         """drain of layer lt (pairs 0..3) with tap 0 of layer lt_next (first local stage lbase_next) issued as its operands
         become ready.  MFMA group (P, K) = output pair P x input group K, 12 MFMAs, ready after drain max(P, K); inside a
         pair the input groups ascend, so every accumulator sees (tap 0: ks 0, 1, 2, 3) in order.  Segment J = the groups
@@ -422,6 +422,8 @@ class Emitter:
         # B_E: every wave has left the main loop (its last stage's slot may be refilled: the DMA of stage 3 follows) and the
         # next layer's stages 0 and 1 have landed
         self.barrier(lbase_next + 1, "BE")
+        if fine is not None:
+            self.stamp(fine, absolute=True)           # fine stamps (stamped bodies): behind the last stage, then behind every segment
         segs = [[(0, 0)], [(1, 0), (0, 1), (1, 1)], [(2, 0), (2, 1), (0, 2), (1, 2), (2, 2)],
                 [(3, 0), (3, 1), (3, 2), (0, 3), (1, 3), (2, 3), (3, 3)]]
         order = [g for sg in segs for g in sg]
@@ -470,6 +472,8 @@ class Emitter:
             emit_f(f)
         dma3 = [("dma", lbase_next + 3, j) for j in range(4)]       # the next layer's stage 3: under the first MFMAs
         for J in range(4):
+            if fine is not None and J > 0:
+                self.stamp(fine + J, absolute=True)
             groups = segs[J]
             # the segment's matrix items: [selector MFMAs of pair J,] then its groups; the loads of a group are emitted
             # behind the MFMAs of the item in front of it (the first item's: in front of the segment)
@@ -809,7 +813,7 @@ def sec_even(stamps, blk):
         e.stamp(0)
         # its epilogue (with the block input x for the skip connection) under tap 0 of the second convolution; the bias row of
         # the next block's first convolution is fetched here (none behind the last block)
-        e.skew(L, L + 1, 18, True, 0, 1, L + 2, True, 1, lead_in=0)
+        e.skew(L, L + 1, 18, True, 0, 1, L + 2, True, 1, lead_in=0, fine=40 if stamps else None)
     else:
         e.comment("---- first convolution of the block: taps 1..7")
         for tap in range(1, 8):
@@ -838,7 +842,7 @@ def sec_x2(stamps, blk):
     e = Emitter(stamps)
     L = 2 * blk + 1
     if SCHEDULE == "skew":
-        e.skew(L, L + 1, 36, False, 1, 0, L + 2, False, 3, lead_in=18)
+        e.skew(L, L + 1, 36, False, 1, 0, L + 2, False, 3, lead_in=18, fine=45 if stamps else None)
     else:
         e.transition(L, L + 1, 18, 36, False, 1, 0, L + 2, False, 3, fine=45 if stamps else None)
     return e

@@ -73,9 +73,9 @@ for variant in [60] + extra + [39]:
         print("  behind the body %d, heads %d, stores %d" % (d(59, prev), d(60, 59), d(61, 60)))
         if s[:, 40].max() > 0 and blocks >= 2:
             kx1, kx2 = 3 + 4 * (blocks - 1), 3 + 4 * (blocks - 2) + 2
-            print("  inside the last block's first transition (tap 8 half 1 | half 2 + drains 0, 1 | groups + drain 2 | groups + drain 3 | rest): %d | %d | %d | %d | %d" % (
+            print("  inside the last block's first boundary (last weight stage + drains 0, 1 | drain-0 rest, group (0,0) + drain 1 | 3 groups + drain 2 | 5 groups + drain 3 | 7 groups, prefetch): %d | %d | %d | %d | %d" % (
                 d(40, kx1), d(41, 40), d(42, 41), d(43, 42), d(kx1 + 1, 43)))
-            print("  inside the last-but-one block's second transition: %d | %d | %d | %d | %d" % (
+            print("  inside the last-but-one block's second boundary: %d | %d | %d | %d | %d" % (
                 d(45, kx2), d(46, 45), d(47, 46), d(48, 47), d(kx2 + 1, 48)))
     else:
         nl = 2 * blocks
