@@ -72,16 +72,14 @@ A_LAST = 223
 
 S_RSRC = 36                        # s[36:39] buffer resource of the weight stream
 S_BLK = 40                         # byte offset of the current block's first stage in the weight stream
-S_PB = 41                          # [4] S_BLK + S_POFF[j]
 S_POFF = 45                        # [4] source offset of this wave's piece j inside a stage
 S_LDST = 49                        # [4] LDS offset of this wave's piece j inside a ring slot
-S_MAX = 53                         # [4] source offset of piece j of the LAST stage (clamp)
 S_CNT = 57                         # blocks left (this one included)
 S_BIASP = 58                       # s[58:59] global address of the next bias row to fetch
 S_WAVE = 60
 S_T = 61                           # temporaries s61, s62
 S_STG = 63                         # source offset of the stage whose pieces are being issued
-S_MAXB = 53                        # source offset of the LAST stage (clamp; = S_MAX[0] without the piece offset)
+S_MAXB = 53                        # source offset of the LAST stage of the tower (clamp of the fetches that run past its end)
 S_TIME = 64                        # s[64:65] s_memtime
 S_STAMP = 66                       # s[66:67] stamp slot 3 + 4 blk of this workgroup
 S_STAMP0 = 68                      # s[68:69] stamp slot 0 of this workgroup (fine stamps inside a transition)
@@ -768,18 +766,14 @@ def sec_head(stamps):
         e.add("s_lshl_b32 s%d, s%d, 13" % (S_T + 1, S_T + 1))                 # (wave & 1) * 32 * 256
         e.add("s_add_u32 s%d, s%d, s%d" % (S_T, S_T, S_T + 1))
         e.add("s_add_u32 s%d, s%d, 0x%x" % (S_POFF + j, S_T, ((j & 1) * 16 + (j >> 1) * 4) * 256))
-        e.add("s_mov_b32 s%d, s%d" % (S_PB + j, S_POFF + j))
         e.add("s_lshl_b32 s%d, s%d, 12" % (S_T, S_WAVE))
         e.add("s_add_u32 s%d, s%d, 0x%x" % (S_LDST + j, S_T, j * 1024))
-        # last stage of the tower: local stage 35 of the last block = blocks * BLOCK_BYTES - 32768 + 128
-        e.add("s_mul_i32 s%d, s%d, 0x%x" % (S_T, S_CNT, BLOCK_BYTES))
-        e.add("s_add_u32 s%d, s%d, s%d" % (S_T, S_T, S_POFF + j))
-        e.add("s_sub_u32 s%d, s%d, 0x%x" % (S_MAX + j, S_T, 32768 - 128))
     e.add("s_waitcnt vmcnt(0)", "vm0")
     # piece j's source offset: the lane's (even / odd piece) + the piece's place in a stage; pieces 2, 3 first (they read
     # V_WSRC[0 / 1], which pieces 0, 1 then overwrite in place)
     for j in (2, 3, 0, 1):
         e.add("v_add_u32 v%d, s%d, v%d" % (V_WSRC4[j], S_POFF + j, V_WSRC + (j & 1)), "valu", wr=[V_WSRC4[j]])
+    # (clamp) the last stage of the tower: local stage 35 of the last block = blocks * BLOCK_BYTES - 32768 + 128
     e.add("s_mul_i32 s%d, s%d, 0x%x" % (S_MAXB, S_CNT, BLOCK_BYTES))
     e.add("s_sub_u32 s%d, s%d, 0x%x" % (S_MAXB, S_MAXB, 32768 - 128))
     return e
@@ -1254,8 +1248,6 @@ def render(stamps):
     put(S["x2_0"])
     lines.append("s_sub_u32 s%d, s%d, 1" % (S_CNT, S_CNT))
     lines.append("s_add_u32 s%d, s%d, 0x%x" % (S_BLK, S_BLK, BLOCK_BYTES))
-    for j in range(4):
-        lines.append("s_add_u32 s%d, s%d, s%d" % (S_PB + j, S_BLK, S_POFF + j))
     if stamps:
         lines.append("s_add_u32 s%d, s%d, 32" % (S_STAMP, S_STAMP))
         lines.append("s_addc_u32 s%d, s%d, 0" % (S_STAMP + 1, S_STAMP + 1))
