@@ -21,9 +21,14 @@
 // row: 8-byte stores.  blockIdx -> tile is XCD-aware: the 12 column tiles of a row block run on one XCD,
 // so the activations are fetched into that L2 once.
 #include "../../include/xq_selfplay.h"
+#include "../../include/xq_debug.h"
 #include "xq_mfma.hpp"
 #include <atomic>
 #include <type_traits>
+
+#ifndef XQ_TOWER_PROBES
+#define XQ_TOWER_PROBES 0
+#endif
 
 namespace {
 using namespace xqm;
@@ -41,6 +46,9 @@ struct FcArgs {
     const int32_t *n_rows;    // optional device value: only rows below *n_rows exist (evaluator row compaction)
 };
 
+// ABL (timing only, wrong results; -DXQ_TOWER_PROBES=1 libraries through xq_policy_fc_debug): 1 = no operand DMA behind the
+// first two stages (what the MFMA stream + fragment reads + barriers take), 2 = no MFMAs (what the operand delivery takes)
+template <int ABL = 0>
 __global__ __launch_bounds__(512, 2) void k_policy_fc(FcArgs P)
 {
     const int tid = threadIdx.x, lane = tid & 63;
@@ -65,6 +73,7 @@ __global__ __launch_bounds__(512, 2) void k_policy_fc(FcArgs P)
     // (row >> 1) & 7 = (lane >> 4) + 4 * (p & 1); pieces are dealt p = j * 8 + wave, so p & 1 = wave & 1
     const int voff = (lane >> 3) * K2 + ((((lane & 7) ^ (lane >> 4)) << 4) ^ ((wave & 1) << 6));
     auto stage_piece = [&](int s, int buf, int j) {                   // j 0..3: activations, 4..6: weights
+        if (ABL == 1 && s >= 2) return;
         if (j < 4) {
             const int p = j * 8 + wave;
             dma16_buf_abs(ra, voff, p * 8 * K2 + s * 128, buf * STAGE_BYTES + p * 1024);
@@ -116,8 +125,10 @@ __global__ __launch_bounds__(512, 2) void k_policy_fc(FcArgs P)
                     if (n >= 4) stage_piece(s2, buf, n + 1);          // pieces 5, 6 ride with tiles 4, 5
                 }
 #pragma unroll
-                for (int mt = 0; mt < 4; mt++)
-                    acc[n][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[cur][n], fx[cur][mt], acc[n][mt], 0, 0, 0);
+                for (int mt = 0; mt < 4; mt++) {
+                    if (ABL == 2) asm volatile("" : : "v"(fw[cur][n]), "v"(fx[cur][mt]));          // (keeps the fragment reads alive)
+                    else acc[n][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[cur][n], fx[cur][mt], acc[n][mt], 0, 0, 0);
+                }
                 const int nrd = kk == 0 ? (n < 4 ? 2 : 1) : (n == 0 ? 0 : n < 5 ? 2 : 1);
                 if (nrd == 2) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
                 else if (nrd == 1) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
@@ -228,9 +239,14 @@ static int fc_lds_opt_in()
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return XQ_E_HIP;
     if (done.load(std::memory_order_acquire) >> dev & 1) return 0;
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_policy_fc), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_policy_fc<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             FC_LDS_BYTES) != hipSuccess)
         return XQ_E_HIP;
+#if XQ_TOWER_PROBES
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_policy_fc<1>), hipFuncAttributeMaxDynamicSharedMemorySize, FC_LDS_BYTES) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_policy_fc<2>), hipFuncAttributeMaxDynamicSharedMemorySize, FC_LDS_BYTES) != hipSuccess)
+        return XQ_E_HIP;
+#endif
     done.fetch_or(1ull << dev, std::memory_order_release);
     return 0;
 }
@@ -245,8 +261,25 @@ extern "C" int xq_policy_fc_bf16(void *stream, const void *act, const void *w, c
     FcArgs a{ (const uint16_t *)act, (const uint16_t *)w, (const float *)bias, (uint16_t *)out, M, N, K, N / BN,
               (const int32_t *)n_rows_dev };
     const int ntiles = ((M + BM - 1) / BM) * (N / BN);
-    hipLaunchKernelGGL(k_policy_fc, dim3(ntiles), dim3(512), FC_LDS_BYTES, reinterpret_cast<hipStream_t>(stream), a);
+    hipLaunchKernelGGL(k_policy_fc<0>, dim3(ntiles), dim3(512), FC_LDS_BYTES, reinterpret_cast<hipStream_t>(stream), a);
     return hipGetLastError() == hipSuccess ? 0 : XQ_E_HIP;
+}
+
+// diagnostic (include/xq_debug.h): the same launch with a timing-only body (wrong results); XQ_E_INVALID in a product library
+extern "C" int xq_policy_fc_debug(int ablate, void *stream, const void *act, const void *w, const void *bias, void *out, int M, int N,
+                                  int K)
+{
+#if XQ_TOWER_PROBES
+    if (!act || !w || !bias || !out || M <= 0 || N <= 0 || K < 64 || (K & 63) || N % BN || ablate < 1 || ablate > 2) return XQ_E_INVALID;
+    if (int rc = fc_lds_opt_in()) return rc;
+    FcArgs a{ (const uint16_t *)act, (const uint16_t *)w, (const float *)bias, (uint16_t *)out, M, N, K, N / BN, nullptr };
+    const int ntiles = ((M + BM - 1) / BM) * (N / BN);
+    if (ablate == 1) hipLaunchKernelGGL(k_policy_fc<1>, dim3(ntiles), dim3(512), FC_LDS_BYTES, reinterpret_cast<hipStream_t>(stream), a);
+    else hipLaunchKernelGGL(k_policy_fc<2>, dim3(ntiles), dim3(512), FC_LDS_BYTES, reinterpret_cast<hipStream_t>(stream), a);
+    return hipGetLastError() == hipSuccess ? 0 : XQ_E_HIP;
+#else
+    return XQ_E_INVALID;
+#endif
 }
 
 /* values[m] = tanh(w2 . relu(w1 . hv[m] + b1) + b2): hv [n_rows][720] bf16 with >= 32 readable bytes behind the last

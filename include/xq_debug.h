@@ -50,6 +50,12 @@ int  xq_conv3x3_debug_stamps(int variant, int ablate, void *hip_stream, const vo
                              const void *bias_dev, const void *residual_dev, void *y_dev, int n_boards, int relu,
                              void *stamps_dev);
 
+/* xq_policy_fc_bf16 with a timing-only body (wrong results): ablate 1 = no operand DMA behind the first two K-stages (what
+ * the MFMA stream, its fragment reads and the stage barriers take), 2 = no MFMAs (what the L2 -> LDS operand delivery takes).
+ * Returns XQ_E_INVALID in a library built without -DXQ_TOWER_PROBES=1. */
+int  xq_policy_fc_debug(int ablate, void *hip_stream, const void *act_dev, const void *w_dev, const void *bias_dev, void *out_dev,
+                        int n_rows, int n_cols, int k);
+
 /* Register budget of k_search_round as minimum waves per SIMD (process-wide): 4 (default, 128 VGPRs), or 3 / 5 / 6 /
  * 8; any other value means 4.  Same results. */
 void xq_engine_set_search_occupancy(int waves_per_simd);
