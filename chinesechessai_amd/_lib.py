@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(CSRC, "libxq_hip.so")
 SOURCES = [os.path.join(CSRC, "xq_engine.hip"), os.path.join(CSRC, "xq_conv.hip"), os.path.join(CSRC, "xq_replay.hip"),
            os.path.join(CSRC, "xq_tower.hip"), os.path.join(CSRC, "xq_policy.hip")]
 HEADERS = [os.path.join(CSRC, "xq_device.hpp"), os.path.join(CSRC, "xq_mfma.hpp"), os.path.join(CSRC, "xq_tower_probes.hpp"),
-           os.path.join(CSRC, "xq_tower1wa.hpp"), os.path.join(CSRC, "xq_tower1wa_body.inc"),
+           os.path.join(CSRC, "xq_tower1wa.hpp"), os.path.join(CSRC, "xq_tower1wa_body.inc"), os.path.join(CSRC, "xq_policy_fc1w_body.inc"),
            os.path.join(_HERE, "..", "include", "xq_selfplay.h"), os.path.join(_HERE, "..", "include", "xq_debug.h")]
 
 MAX_MOVES = 128
@@ -192,6 +192,8 @@ _DEBUG_SIGNATURES = {
     "xq_conv3x3_set_variant": (None, [C.c_int]),
     "xq_conv3x3_debug_stamps": (C.c_int, [C.c_int, C.c_int] + [C.c_void_p] * 6 + [C.c_int, C.c_int, C.c_void_p]),
     "xq_engine_set_search_occupancy": (None, [C.c_int]),
+    "xq_policy_fc_set_variant": (None, [C.c_int]),
+    "xq_policy_fc_debug_stamps": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "xq_policy_fc_debug": (C.c_int, [C.c_int] + [C.c_void_p] * 5 + [C.c_int, C.c_int, C.c_int]),
 }
 

@@ -44,6 +44,7 @@ struct FcArgs {
     uint16_t *out;            // [M][N]
     int M, N, K, ncol;
     const int32_t *n_rows;    // optional device value: only rows below *n_rows exist (evaluator row compaction)
+    unsigned long long *stamps;   // (stamped probe bodies of k_policy_fc1w only: 8 uint64 per wave, 32 per workgroup)
 };
 
 // ABL (timing only, wrong results; -DXQ_TOWER_PROBES=1 libraries through xq_policy_fc_debug): 1 = no operand DMA behind the
@@ -179,6 +180,89 @@ __global__ __launch_bounds__(512, 2) void k_policy_fc(FcArgs P)
 
 
 // ------------------------------------------------------------------------------------------
+// k_policy_fc1w (round 4): the same GEMM with ONE wave per SIMD and its whole body - operand DMA, K loop, epilogue - as one
+// asm statement generated and checked by tools/gen_policy_fc1w.py (the design and its reasons are in that file's header and in
+// DESIGN.md section 5): 256-thread workgroup, wave tile 96 columns x 128 rows (6 x 8 MFMA tiles, accumulators on a[0:191]),
+// K-stages of 64 as whole 128-B cache lines through two ring slots, one barrier per 96 MFMAs, fragments double-buffered in
+// registers, two instructions per DMA piece, 16-byte output stores.  Same fp32 chain per output element as k_policy_fc (K
+// ascending in 32-wide MFMA steps, weights as the A operand, bias added last): the two kernels agree to the bit, for every K
+// that is a multiple of 64.
+// ------------------------------------------------------------------------------------------
+#include "xq_policy_fc1w_body.inc"
+#if XQ_TOWER_PROBES
+#include "xq_policy_fc1w_abl.inc"      // timing-only bodies (wrong results): python tools/gen_policy_fc1w.py --ablations
+#endif
+#define XQ_FV8(b) "v" #b "0", "v" #b "1", "v" #b "2", "v" #b "3", "v" #b "4", "v" #b "5", "v" #b "6", "v" #b "7", "v" #b "8", "v" #b "9"
+#define XQ_FA8(b) "a" #b "0", "a" #b "1", "a" #b "2", "a" #b "3", "a" #b "4", "a" #b "5", "a" #b "6", "a" #b "7", "a" #b "8", "a" #b "9"
+#define XQ_FS8(b) "s" #b "0", "s" #b "1", "s" #b "2", "s" #b "3", "s" #b "4", "s" #b "5", "s" #b "6", "s" #b "7", "s" #b "8", "s" #b "9"
+static_assert(XQ_FC1W_V_LAST == 177 && XQ_FC1W_S_FIRST == 36 && XQ_FC1W_S_LAST == 97, "clobber list of the FC body");
+
+// ABL (probes builds): 2 / 5 = other placements of a stage's DMA pieces (same results), 3 = no operand DMA behind the prologue,
+// 4 = no MFMAs, 6 = no MFMAs and no fragment reads (wrong results), 7 / 8 = the product / body 3 with phase stamps
+#define XQ_FC1W_ASM(BODY)                                                                                                          \
+    asm volatile(BODY                                                                                                              \
+                 :                                                                                                                 \
+                 : "s"(act_t), "s"(act_bytes), "s"(w_t), "s"(w_bytes), "s"(out_t), "s"(wave), "s"(K2), "s"(nst), "s"(N2), "s"(rows), \
+                   "s"(bias_t), "v"(vfa), "v"(vfb), "v"(vdma), "v"(vstore), "v"(vrow), "v"(vbias), "s"(stamp_p), "v"(vdmaw)        \
+                 : "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", XQ_FV8(1), XQ_FV8(2), XQ_FV8(3), XQ_FV8(4), XQ_FV8(5), XQ_FV8(6), \
+                   XQ_FV8(7), XQ_FV8(8), XQ_FV8(9), XQ_FV8(10), XQ_FV8(11), XQ_FV8(12), XQ_FV8(13), XQ_FV8(14), XQ_FV8(15), XQ_FV8(16), \
+                   "v170", "v171", "v172", "v173", "v174", "v175", "v176", "v177",                                                 \
+                   "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", XQ_FA8(1), XQ_FA8(2), XQ_FA8(3), XQ_FA8(4), XQ_FA8(5), XQ_FA8(6), \
+                   XQ_FA8(7), XQ_FA8(8), XQ_FA8(9), XQ_FA8(10), XQ_FA8(11), XQ_FA8(12), XQ_FA8(13), XQ_FA8(14), XQ_FA8(15), XQ_FA8(16), \
+                   XQ_FA8(17), XQ_FA8(18), "a190", "a191",                                                                         \
+                   "s36", "s37", "s38", "s39", XQ_FS8(4), XQ_FS8(5), XQ_FS8(6), XQ_FS8(7), XQ_FS8(8), "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "vcc", "scc", "memory")
+
+template <int ABL = 0>
+__global__ __launch_bounds__(256, 1) void k_policy_fc1w(FcArgs P)
+{
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r16 = lane & 15, q = lane >> 4;
+    // XCD-aware, bijective blockIdx -> tile, as in k_policy_fc
+    const int nwg = gridDim.x, orig = blockIdx.x, xcd = orig & 7, qd = nwg >> 3, rem = nwg & 7;
+    const int t = (xcd < rem ? xcd * (qd + 1) : rem * (qd + 1) + (xcd - rem) * qd) + (orig >> 3);
+    const int rb = t / P.ncol, cb = t - rb * P.ncol;
+    const int m0 = rb * BM, n0 = cb * BN;
+    int M = P.M;
+    if (P.n_rows) { const int n = *P.n_rows; M = n < M ? n : M; }
+    if (m0 >= M) return;                                              // compaction: no row in this tile
+    const int rows = M - m0 < BM ? M - m0 : BM;                       // rows past M read as zeros (buffer bounds), are not stored
+    const int K2 = P.K * 2, N2 = P.N * 2, nst = P.K >> 6;
+    const uint16_t *act_t = P.act + (size_t)m0 * P.K;
+    const uint16_t *w_t = P.w + (size_t)n0 * P.K;
+    uint16_t *out_t = P.out + (size_t)m0 * P.N + n0;
+    const float *bias_t = P.bias + n0;
+    const int act_bytes = rows * K2, w_bytes = BN * K2;
+    // LDS image of a stage: 256 activation rows, then (at 32,768) 192 weight rows, 128 B (64 bf16) each; chunk c of a row sits
+    // at chunk c ^ g.  Activations: g = (row >> 1) & 7 - the 16 lanes one ds_read_b128 cycle serves (lanes {0-3, 12-15, 20-27},
+    // ...) then cover all 16 (row & 1, chunk) positions of the 256-B bank row.  Weights: MFMA row i of tile at reads weight row
+    // 32 (at >> 1) + 4 (at & 1) + 8 (i >> 2) + (i & 3) (a lane then holds 8 consecutive output columns of a tile pair) and g is
+    // the same function of i - for weight row n that is 2 ((n >> 3) & 3) + ((n >> 1) & 1).  The DMA lands lane l at byte 16 l of
+    // its piece (8 rows x 128 B, piece p = wave + 4 j), so the swizzle is in what each lane fetches.
+    const int gr = (r16 >> 1) & 7;
+    const int vfa = (wn * 96 + 8 * (r16 >> 2) + (r16 & 3)) * 128 + ((q ^ gr) << 4);   // weight fragment (K half 0, ring slot 0; + 32,768 in the body)
+    const int vfb = (wm * 128 + r16) * 128 + ((q ^ gr) << 4);                                    // activation fragment
+    const int ga = 4 * (wave & 1) + ((lane >> 4) & 3), gw = 2 * wave + ((lane >> 4) & 1);
+    const int vdma = (lane >> 3) * K2 + (((lane & 7) ^ ga) << 4);
+    const int vdmaw = (lane >> 3) * K2 + (((lane & 7) ^ gw) << 4);
+    const int vstore = ((wm * 128 + r16) * P.N + wn * 96 + 8 * q) * 2;
+    const int vrow = wm * 128 + r16;
+    const int vbias = (wn * 96 + 8 * q) * 4;
+    unsigned long long *stamp_p = ABL >= 7 ? P.stamps + (size_t)blockIdx.x * 32 : nullptr;
+#if XQ_TOWER_PROBES
+    if constexpr (ABL == 7) { XQ_FC1W_ASM(XQ_FC1W_BODY_STAMPED); return; }
+    if constexpr (ABL == 8) { XQ_FC1W_ASM(XQ_FC1W_BODY_NODMA_STAMPED); return; }
+    if constexpr (ABL == 2) { XQ_FC1W_ASM(XQ_FC1W_BODY_FRONT); return; }
+    if constexpr (ABL == 3) { XQ_FC1W_ASM(XQ_FC1W_BODY_NODMA); return; }
+    if constexpr (ABL == 4) { XQ_FC1W_ASM(XQ_FC1W_BODY_NOMFMA); return; }
+    if constexpr (ABL == 5) { XQ_FC1W_ASM(XQ_FC1W_BODY_EVEN); return; }
+    if constexpr (ABL == 6) { XQ_FC1W_ASM(XQ_FC1W_BODY_NOMFMA_NOLDS); return; }
+#endif
+    XQ_FC1W_ASM(XQ_FC1W_BODY);
+}
+
+// ------------------------------------------------------------------------------------------
 // Value head behind the 1x1 convolution (neural_network.py:43-45,66-69): v = tanh(fc2(relu(fc1(hv)))).
 // 184 KB of fc1 weights, 92 kMAC per row: one wave per 16 rows, fragments straight from global memory
 // (L2-resident weights, each activation byte read once), 8 x 23 MFMAs, the 128 hidden units stay in the
@@ -233,6 +317,14 @@ __global__ __launch_bounds__(256) void k_value_head(const uint16_t *__restrict__
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is per device: remembered per device ordinal (a process may drive
 // several GPUs, xq_config.device)
+// -1 / 0 = k_policy_fc (8 waves, HIP: the product), 1 = k_policy_fc1w.  k_policy_fc1w takes 152-156 us where k_policy_fc takes 175-200
+// (16,384 rows, alternating in one process), and the self-play step is 0.6 % LONGER with it: the trunk kernel that runs around it
+// then holds 2.10 instead of 2.145 GHz (profiles/r04c_ab_policy_fc.txt; DVFS give-back) - so the default is
+// the kernel that is slower on its own.
+static int g_fc_variant = -1;
+// diagnostic switch (include/xq_debug.h): both kernels compute the same bits
+extern "C" void xq_policy_fc_set_variant(int v) { g_fc_variant = v; }
+
 static int fc_lds_opt_in()
 {
     static std::atomic<uint64_t> done{ 0 };
@@ -242,7 +334,18 @@ static int fc_lds_opt_in()
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_policy_fc<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             FC_LDS_BYTES) != hipSuccess)
         return XQ_E_HIP;
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_policy_fc1w<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            XQ_FC1W_LDS_BYTES) != hipSuccess)
+        return XQ_E_HIP;
 #if XQ_TOWER_PROBES
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_policy_fc1w<2>), hipFuncAttributeMaxDynamicSharedMemorySize, XQ_FC1W_LDS_BYTES) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_policy_fc1w<3>), hipFuncAttributeMaxDynamicSharedMemorySize, XQ_FC1W_LDS_BYTES) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_policy_fc1w<4>), hipFuncAttributeMaxDynamicSharedMemorySize, XQ_FC1W_LDS_BYTES) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_policy_fc1w<5>), hipFuncAttributeMaxDynamicSharedMemorySize, XQ_FC1W_LDS_BYTES) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_policy_fc1w<6>), hipFuncAttributeMaxDynamicSharedMemorySize, XQ_FC1W_LDS_BYTES) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_policy_fc1w<7>), hipFuncAttributeMaxDynamicSharedMemorySize, XQ_FC1W_LDS_BYTES) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_policy_fc1w<8>), hipFuncAttributeMaxDynamicSharedMemorySize, XQ_FC1W_LDS_BYTES) != hipSuccess)
+        return XQ_E_HIP;
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_policy_fc<1>), hipFuncAttributeMaxDynamicSharedMemorySize, FC_LDS_BYTES) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void *>(&k_policy_fc<2>), hipFuncAttributeMaxDynamicSharedMemorySize, FC_LDS_BYTES) != hipSuccess)
         return XQ_E_HIP;
@@ -259,9 +362,24 @@ extern "C" int xq_policy_fc_bf16(void *stream, const void *act, const void *w, c
     if (!act || !w || !bias || !out || M <= 0 || N <= 0 || K < 64 || (K & 63) || N % BN) return XQ_E_INVALID;
     if (int rc = fc_lds_opt_in()) return rc;
     FcArgs a{ (const uint16_t *)act, (const uint16_t *)w, (const float *)bias, (uint16_t *)out, M, N, K, N / BN,
-              (const int32_t *)n_rows_dev };
+              (const int32_t *)n_rows_dev, nullptr };
     const int ntiles = ((M + BM - 1) / BM) * (N / BN);
-    hipLaunchKernelGGL(k_policy_fc<0>, dim3(ntiles), dim3(512), FC_LDS_BYTES, reinterpret_cast<hipStream_t>(stream), a);
+#if XQ_TOWER_PROBES
+    if (g_fc_variant >= 2 && g_fc_variant <= 6) {
+        const hipStream_t hs = reinterpret_cast<hipStream_t>(stream);
+        if (g_fc_variant == 2) hipLaunchKernelGGL(k_policy_fc1w<2>, dim3(ntiles), dim3(256), XQ_FC1W_LDS_BYTES, hs, a);
+        if (g_fc_variant == 3) hipLaunchKernelGGL(k_policy_fc1w<3>, dim3(ntiles), dim3(256), XQ_FC1W_LDS_BYTES, hs, a);
+        if (g_fc_variant == 4) hipLaunchKernelGGL(k_policy_fc1w<4>, dim3(ntiles), dim3(256), XQ_FC1W_LDS_BYTES, hs, a);
+        if (g_fc_variant == 5) hipLaunchKernelGGL(k_policy_fc1w<5>, dim3(ntiles), dim3(256), XQ_FC1W_LDS_BYTES, hs, a);
+        if (g_fc_variant == 6) hipLaunchKernelGGL(k_policy_fc1w<6>, dim3(ntiles), dim3(256), XQ_FC1W_LDS_BYTES, hs, a);
+        return hipGetLastError() == hipSuccess ? 0 : XQ_E_HIP;
+    }
+#endif
+    if (g_fc_variant > 1) return XQ_E_INVALID;
+    if (g_fc_variant == 1)
+        hipLaunchKernelGGL(k_policy_fc1w<0>, dim3(ntiles), dim3(256), XQ_FC1W_LDS_BYTES, reinterpret_cast<hipStream_t>(stream), a);
+    else
+        hipLaunchKernelGGL(k_policy_fc<0>, dim3(ntiles), dim3(512), FC_LDS_BYTES, reinterpret_cast<hipStream_t>(stream), a);
     return hipGetLastError() == hipSuccess ? 0 : XQ_E_HIP;
 }
 
@@ -272,10 +390,29 @@ extern "C" int xq_policy_fc_debug(int ablate, void *stream, const void *act, con
 #if XQ_TOWER_PROBES
     if (!act || !w || !bias || !out || M <= 0 || N <= 0 || K < 64 || (K & 63) || N % BN || ablate < 1 || ablate > 2) return XQ_E_INVALID;
     if (int rc = fc_lds_opt_in()) return rc;
-    FcArgs a{ (const uint16_t *)act, (const uint16_t *)w, (const float *)bias, (uint16_t *)out, M, N, K, N / BN, nullptr };
+    FcArgs a{ (const uint16_t *)act, (const uint16_t *)w, (const float *)bias, (uint16_t *)out, M, N, K, N / BN, nullptr, nullptr };
     const int ntiles = ((M + BM - 1) / BM) * (N / BN);
     if (ablate == 1) hipLaunchKernelGGL(k_policy_fc<1>, dim3(ntiles), dim3(512), FC_LDS_BYTES, reinterpret_cast<hipStream_t>(stream), a);
     else hipLaunchKernelGGL(k_policy_fc<2>, dim3(ntiles), dim3(512), FC_LDS_BYTES, reinterpret_cast<hipStream_t>(stream), a);
+    return hipGetLastError() == hipSuccess ? 0 : XQ_E_HIP;
+#else
+    return XQ_E_INVALID;
+#endif
+}
+
+/* k_policy_fc1w with phase stamps (probes library; include/xq_debug.h) */
+extern "C" int xq_policy_fc_debug_stamps(int nodma, void *stream, const void *act, const void *w, const void *bias, void *out, int M, int N,
+                                         int K, void *stamps_dev)
+{
+#if XQ_TOWER_PROBES
+    if (!act || !w || !bias || !out || !stamps_dev || M <= 0 || N <= 0 || (K & 63) || N % BN) return XQ_E_INVALID;
+    if (int rc = fc_lds_opt_in()) return rc;
+    FcArgs a{ (const uint16_t *)act, (const uint16_t *)w, (const float *)bias, (uint16_t *)out, M, N, K, N / BN, nullptr,
+              (unsigned long long *)stamps_dev };
+    const int ntiles = ((M + BM - 1) / BM) * (N / BN);
+    const hipStream_t hs = reinterpret_cast<hipStream_t>(stream);
+    if (nodma) hipLaunchKernelGGL(k_policy_fc1w<8>, dim3(ntiles), dim3(256), XQ_FC1W_LDS_BYTES, hs, a);
+    else hipLaunchKernelGGL(k_policy_fc1w<7>, dim3(ntiles), dim3(256), XQ_FC1W_LDS_BYTES, hs, a);
     return hipGetLastError() == hipSuccess ? 0 : XQ_E_HIP;
 #else
     return XQ_E_INVALID;

@@ -50,11 +50,24 @@ int  xq_conv3x3_debug_stamps(int variant, int ablate, void *hip_stream, const vo
                              const void *bias_dev, const void *residual_dev, void *y_dev, int n_boards, int relu,
                              void *stamps_dev);
 
+/* Kernel behind xq_policy_fc_bf16 (process-wide): -1 or 0 = k_policy_fc (8 waves, HIP: the product), 1 = k_policy_fc1w (one
+ * wave per SIMD, generated asm body: 13-20 % faster on its own, 0.6 % slower end to end - the trunk kernel's clock pays for it,
+ * DESIGN.md section 5).  Same bits.  2..6 = other DMA placements and timing-only bodies of k_policy_fc1w in a
+ * -DXQ_TOWER_PROBES=1 library (3, 4: wrong results); in the default library xq_policy_fc_bf16 answers XQ_E_INVALID while one
+ * of them is selected. */
+void xq_policy_fc_set_variant(int variant);
+
 /* xq_policy_fc_bf16 with a timing-only body (wrong results): ablate 1 = no operand DMA behind the first two K-stages (what
  * the MFMA stream, its fragment reads and the stage barriers take), 2 = no MFMAs (what the L2 -> LDS operand delivery takes).
  * Returns XQ_E_INVALID in a library built without -DXQ_TOWER_PROBES=1. */
 int  xq_policy_fc_debug(int ablate, void *hip_stream, const void *act_dev, const void *w_dev, const void *bias_dev, void *out_dev,
                         int n_rows, int n_cols, int k);
+
+/* k_policy_fc1w with phase stamps: 8 uint64 per wave (32 per workgroup, workgroup = blockIdx) into stamps_dev: s_memtime at
+ * start / first K-stage landed / K loop done / all stored, then s_memrealtime at start / end.  nodma != 0: the timing-only body
+ * without operand DMA behind the prologue.  Returns XQ_E_INVALID in a library built without -DXQ_TOWER_PROBES=1. */
+int  xq_policy_fc_debug_stamps(int nodma, void *hip_stream, const void *act_dev, const void *w_dev, const void *bias_dev,
+                               void *out_dev, int n_rows, int n_cols, int k, void *stamps_dev);
 
 /* Register budget of k_search_round as minimum waves per SIMD (process-wide): 4 (default, 128 VGPRs), or 3 / 5 / 6 /
  * 8; any other value means 4.  Same results. */

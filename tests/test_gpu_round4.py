@@ -299,3 +299,72 @@ def test_north_star_names_and_the_fp32_notice(L):
     assert len(r) == 2 and len(r2) == 2
     notices = [x for x in w if issubclass(x.category, RuntimeWarning) and "library kernels" in str(x.message)]
     assert len(notices) == 1                                   # said once, not per call
+
+
+def test_policy_fc_one_wave_body_equals_the_hip_kernel(L):
+    """k_policy_fc1w (one wave per SIMD, generated asm body; selectable, include/xq_debug.h) against k_policy_fc (8 waves, HIP)
+    on the same operands: same bits for both policy layouts, ragged and tiny row counts, a row count read from the device
+    (row compaction), nothing written past the last row, other K (one, two, an even number of K-stages)."""
+    import torch
+    st = torch.cuda.current_stream().cuda_stream
+    K = 2880
+    g = torch.Generator(device="cuda").manual_seed(11)
+    Mmax = 4097
+    act_all = (torch.randn(Mmax, K, device="cuda", generator=g) * (torch.rand(Mmax, K, device="cuda", generator=g) < 0.5)).bfloat16()
+    try:
+        for N in (2304, 8256):
+            w = (torch.randn(N, K, device="cuda", generator=g) * 0.05).bfloat16()
+            bias = torch.randn(N, device="cuda", generator=g)
+            for M in (1, 16, 37, 255, 256, 257, 300, 1024, Mmax):
+                act = act_all[:M].contiguous()
+                outs = []
+                for variant in (0, 1, -1):
+                    L.xq_policy_fc_set_variant(variant)
+                    out = torch.full((M + 1, N), 7.0, dtype=torch.bfloat16, device="cuda")
+                    assert L.xq_policy_fc_bf16(st, act.data_ptr(), w.data_ptr(), bias.data_ptr(), out.data_ptr(), M, N, K, None) == 0
+                    torch.cuda.synchronize()
+                    assert (out[M] == 7.0).all(), (N, M, variant)
+                    outs.append(out)
+                assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2]), (N, M, (outs[0].float() - outs[1].float()).abs().max().item())
+                ref = act.float() @ w.float().t() + bias
+                assert (outs[1][:M].float() - ref).abs().max().item() <= 2 ** -8 * max(1.0, ref.abs().max().item())
+            # row count on the device: rows behind it stay untouched, tiles behind it are not run
+            n_rows = torch.tensor([700], dtype=torch.int32, device="cuda")
+            act = act_all[:2048].contiguous()
+            outs = []
+            for variant in (0, 1):
+                L.xq_policy_fc_set_variant(variant)
+                out = torch.full((2048, N), 7.0, dtype=torch.bfloat16, device="cuda")
+                assert L.xq_policy_fc_bf16(st, act.data_ptr(), w.data_ptr(), bias.data_ptr(), out.data_ptr(), 2048, N, K, n_rows.data_ptr()) == 0
+                torch.cuda.synchronize()
+                assert (out[700:] == 7.0).all()
+                outs.append(out)
+            assert torch.equal(outs[0], outs[1])
+        # another K (46 K-stages of 64, an even count), few rows
+        K2 = 2944
+        act = (torch.randn(300, K2, device="cuda", generator=g)).bfloat16()
+        w = (torch.randn(2304, K2, device="cuda", generator=g) * 0.05).bfloat16()
+        bias = torch.randn(2304, device="cuda", generator=g)
+        outs = []
+        for variant in (0, 1):
+            L.xq_policy_fc_set_variant(variant)
+            out = torch.empty(300, 2304, dtype=torch.bfloat16, device="cuda")
+            assert L.xq_policy_fc_bf16(st, act.data_ptr(), w.data_ptr(), bias.data_ptr(), out.data_ptr(), 300, 2304, K2, None) == 0
+            torch.cuda.synchronize()
+            outs.append(out)
+        assert torch.equal(outs[0], outs[1])
+        ref = act.float() @ w.float().t() + bias
+        assert (outs[1].float() - ref).abs().max().item() <= 2 ** -8 * max(1.0, ref.abs().max().item())
+        for K3 in (64, 128):                                   # one and two K-stages
+            act = (torch.randn(70, K3, device="cuda", generator=g)).bfloat16()
+            w = (torch.randn(192, K3, device="cuda", generator=g) * 0.05).bfloat16()
+            outs = []
+            for variant in (0, 1):
+                L.xq_policy_fc_set_variant(variant)
+                out = torch.empty(70, 192, dtype=torch.bfloat16, device="cuda")
+                assert L.xq_policy_fc_bf16(st, act.data_ptr(), w.data_ptr(), bias.data_ptr(), out.data_ptr(), 70, 192, K3, None) == 0
+                torch.cuda.synchronize()
+                outs.append(out)
+            assert torch.equal(outs[0], outs[1]), K3
+    finally:
+        L.xq_policy_fc_set_variant(-1)

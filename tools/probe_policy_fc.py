@@ -1,4 +1,4 @@
-"""k_policy_fc against its two timing-only bodies (probes library: XQ_TOWER_PROBES=1), interleaved in one process (run on the
+"""k_policy_fc against k_policy_fc1w and against its two timing-only bodies (probes library: XQ_TOWER_PROBES=1), interleaved in one process (run on the
 GPU box): what the MFMA stream alone takes, what the operand delivery alone takes, and the kernel.  usage: probe_policy_fc.py [M=16384]"""
 import os
 import sys
@@ -31,7 +31,20 @@ def timeit(fn, it=20):
     return e0.elapsed_time(e1) / it * 1e3
 
 
-cases = (("kernel", lambda: L.xq_policy_fc_bf16(st, act.data_ptr(), w.data_ptr(), bias.data_ptr(), out.data_ptr(), M, N, K, None)),
+def variant(v):
+    def fn():
+        L.xq_policy_fc_set_variant(v)
+        r = L.xq_policy_fc_bf16(st, act.data_ptr(), w.data_ptr(), bias.data_ptr(), out.data_ptr(), M, N, K, None)
+        L.xq_policy_fc_set_variant(-1)
+        return r
+    return fn
+
+
+cases = (("k_policy_fc (8 waves, HIP)", variant(0)), ("k_policy_fc1w (one wave per SIMD, asm body)", variant(1)),
+         ("k_policy_fc1w, one barrier, pieces 12 + 2", variant(2)), ("k_policy_fc1w, two barriers, pieces 5 + 9", variant(5)), ("k_policy_fc1w, no operand DMA behind the prologue", variant(3)),
+         ("k_policy_fc1w, no MFMAs", variant(4)),
+         ("k_policy_fc1w, one barrier, pieces 14 + 0", variant(6)),
+         ("kernel", lambda: L.xq_policy_fc_bf16(st, act.data_ptr(), w.data_ptr(), bias.data_ptr(), out.data_ptr(), M, N, K, None)),
          ("no operand DMA behind the first two stages", lambda: L.xq_policy_fc_debug(1, st, act.data_ptr(), w.data_ptr(), bias.data_ptr(), out.data_ptr(), M, N, K)),
          ("no MFMAs", lambda: L.xq_policy_fc_debug(2, st, act.data_ptr(), w.data_ptr(), bias.data_ptr(), out.data_ptr(), M, N, K)))
 for rep in range(2):
@@ -40,5 +53,5 @@ for rep in range(2):
             print("%s: not in this library (XQ_TOWER_PROBES=1)" % name)
             continue
         us = timeit(fn)
-        print("%-46s %7.1f us  %6.1f TFLOP/s equivalent = %.3f of 2.5 PFLOP/s; operand stream %.2f TB/s" % (
+        print("%-52s %7.1f us  %6.1f TFLOP/s equivalent = %.3f of 2.5 PFLOP/s; operand stream %.2f TB/s" % (
             name, us, fl / us / 1e6, fl / us / 1e6 / 2500.0, (M / 256) * (N / 192) * (K / 64) * 57344 / us / 1e6), flush=True)
