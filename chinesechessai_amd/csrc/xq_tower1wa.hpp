@@ -414,7 +414,9 @@ __global__ __launch_bounds__(256, 1) void k_tower1wa(TowerArgs A)
         }
 #pragma unroll
         for (int m = 0; m < 3; m++) {
-            const int row = m * 16 + r16;
+            // policy channels (tiles 0, 1): MFMA row i of tile m is channel 8 (i >> 2) + 4 m + (i & 3), so that a lane ends up
+            // with 8 consecutive channels of its pixel (one 16-byte store; the four lanes of a pixel write its whole 64-B row)
+            const int row = m < 2 ? 8 * (r16 >> 2) + 4 * m + (r16 & 3) : m * 16 + r16;
             ha[m] = lds_ld128(row * 256 + (((ks * 4 + q) ^ ((row & 7) << 1)) << 4));
         }
 #pragma unroll
@@ -426,19 +428,30 @@ __global__ __launch_bounds__(256, 1) void k_tower1wa(TowerArgs A)
     stamp(60);
     uint8_t *Pb = reinterpret_cast<uint8_t *>(A.P) + (size_t)board * PIX * 64;
     uint8_t *Vb = reinterpret_cast<uint8_t *>(A.V) + (size_t)board * PIX * 16;
-#pragma unroll
-    for (int m = 0; m < 3; m++) {
-        const int c0 = m * 16 + 4 * q;                               // head channel of element 0
-        const f32x4 b4 = *reinterpret_cast<const f32x4 *>(A.bh + c0);
+    {
+        // policy head: channels 8 q .. 8 q + 7 of pixel p (tiles 0 and 1), bias, bf16, ReLU, 16 bytes; a store instruction
+        // writes 16 pixels x 64 B = 1 KB contiguously
+        const f32x4 b0 = *reinterpret_cast<const f32x4 *>(A.bh + 8 * q), b1 = *reinterpret_cast<const f32x4 *>(A.bh + 8 * q + 4);
 #pragma unroll
         for (int nt = 0; nt < 6; nt++) {
             const int p = nt * 16 + r16;
-            if (board_ok && p < PIX && (m < 2 || q < 2)) {           // value head: channels 32..39 only
-                const float v0 = hacc[m][nt][0] + b4[0], v1 = hacc[m][nt][1] + b4[1];
-                const float v2 = hacc[m][nt][2] + b4[2], v3 = hacc[m][nt][3] + b4[3];
-                const uint2 pk = make_uint2(relu_bf16x2(pack_bf16x2(v0, v1)), relu_bf16x2(pack_bf16x2(v2, v3)));
-                if (m < 2) *reinterpret_cast<uint2 *>(Pb + p * 64 + c0 * 2) = pk;
-                else *reinterpret_cast<uint2 *>(Vb + p * 16 + (c0 - 32) * 2) = pk;
+            if (board_ok && p < PIX) {
+                const uint4 pk = make_uint4(relu_bf16x2(pack_bf16x2(hacc[0][nt][0] + b0[0], hacc[0][nt][1] + b0[1])),
+                                            relu_bf16x2(pack_bf16x2(hacc[0][nt][2] + b0[2], hacc[0][nt][3] + b0[3])),
+                                            relu_bf16x2(pack_bf16x2(hacc[1][nt][0] + b1[0], hacc[1][nt][1] + b1[1])),
+                                            relu_bf16x2(pack_bf16x2(hacc[1][nt][2] + b1[2], hacc[1][nt][3] + b1[3])));
+                *reinterpret_cast<uint4 *>(Pb + p * 64 + q * 16) = pk;
+            }
+        }
+        // value head: channels 32 + 4 q .. (q < 2) of tile 2
+        const f32x4 b4 = *reinterpret_cast<const f32x4 *>(A.bh + 32 + 4 * q);
+#pragma unroll
+        for (int nt = 0; nt < 6; nt++) {
+            const int p = nt * 16 + r16;
+            if (board_ok && p < PIX && q < 2) {
+                const uint2 pk = make_uint2(relu_bf16x2(pack_bf16x2(hacc[2][nt][0] + b4[0], hacc[2][nt][1] + b4[1])),
+                                            relu_bf16x2(pack_bf16x2(hacc[2][nt][2] + b4[2], hacc[2][nt][3] + b4[3])));
+                *reinterpret_cast<uint2 *>(Vb + p * 16 + q * 8) = pk;
             }
         }
     }
