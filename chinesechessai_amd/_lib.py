@@ -6,6 +6,7 @@ gfx950 device is visible, every compute entry point raises — loudly.
 import ctypes as C
 import os
 import subprocess
+import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
@@ -63,6 +64,10 @@ def build(force=False, verbose=False):
     flags = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
     if probes:
         flags.append("-DXQ_TOWER_PROBES=1")
+        # the timing-only bodies of the two generated asm statements are not committed: write them first
+        tools = os.path.join(os.path.dirname(os.path.dirname(CSRC)), "tools")
+        for gen in ("gen_tower1wa.py", "gen_policy_fc1w.py"):
+            subprocess.check_call([sys.executable, os.path.join(tools, gen), "--ablations"], stdout=subprocess.DEVNULL)
     objdir = os.path.join(CSRC, "build")
     os.makedirs(objdir, exist_ok=True)
     jobs, tower_rebuilt = [], False
