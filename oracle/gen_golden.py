@@ -31,7 +31,8 @@ with contextlib.redirect_stdout(io.StringIO()):
     import chess_env  # noqa: E402
     import self_play  # noqa: E402
 
-OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+# (XQ_GOLDEN_OUT: tests/test_golden_regen_cpu.py regenerates into a scratch directory and compares bytes)
+OUT = os.environ.get("XQ_GOLDEN_OUT") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
 os.makedirs(OUT, exist_ok=True)
 
 WINNER_NONE = 2
