@@ -476,13 +476,15 @@ def run_rank(args):
     clock_buf = torch.zeros(3, dtype=torch.int64, device="cuda")
     torch.cuda.synchronize()
     _lib.lib().xq_tower_set_clock_sample(clock_buf.data_ptr())
-    t0 = time.time()
-    for k in range(args.steps):
-        step(eng, ev, k * TG * world)
-    sync()
-    dt = time.time() - t0
+    try:
+        t0 = time.time()
+        for k in range(args.steps):
+            step(eng, ev, k * TG * world)
+        sync()
+        dt = time.time() - t0
+    finally:                # (the library keeps a raw pointer: never leave it behind, whatever the timed loop did)
+        _lib.lib().xq_tower_set_clock_sample(None)
     tm.on(False)
-    _lib.lib().xq_tower_set_clock_sample(None)
     clk = clock_buf.cpu().numpy()
     trunk_clock_ghz = float(clk[0]) / float(clk[1]) * 0.1 if clk[1] > 0 else None
     prof = eng.profile_read()
@@ -653,7 +655,8 @@ def run_rank(args):
                                  n_fw, int(rows_fw.sum()), fw_ms / max(n_fw, 1)),
                              "flops_per_row": fl, "rows_evaluated": int(rows_fw.sum()), "note": rows_note},
             # the whole step against the MFMA peak: every network row evaluated x its flops, over the WALL time of the timed region
-            "end_to_end_mfma_frac": float(fl * rows_fw.sum()) / dt / 1e12 / MFMA_PEAK_BF16_TFLOPS / world,
+            # (per GPU: rank 0's rows over the max-over-ranks time against ONE GPU's peak; every rank plays the same number of games)
+            "end_to_end_mfma_frac": float(fl * rows_fw.sum()) / dt / 1e12 / MFMA_PEAK_BF16_TFLOPS,
             "roofline_tree": {"bound": "hbm", "achieved": tree_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": tree_gbs / HBM_PEAK_GBS, "traffic": tr_tree[0], "traffic_source": tr_tree[1],
                               "kernel": "k_search_round (%d launches, %.3f ms avg)" % (

@@ -405,7 +405,7 @@ extern "C" int xq_policy_fc_debug_stamps(int nodma, void *stream, const void *ac
                                          int K, void *stamps_dev)
 {
 #if XQ_TOWER_PROBES
-    if (!act || !w || !bias || !out || !stamps_dev || M <= 0 || N <= 0 || (K & 63) || N % BN) return XQ_E_INVALID;
+    if (!act || !w || !bias || !out || !stamps_dev || M <= 0 || N <= 0 || K < 64 || (K & 63) || N % BN) return XQ_E_INVALID;
     if (int rc = fc_lds_opt_in()) return rc;
     FcArgs a{ (const uint16_t *)act, (const uint16_t *)w, (const float *)bias, (uint16_t *)out, M, N, K, N / BN, nullptr,
               (unsigned long long *)stamps_dev };

@@ -782,10 +782,27 @@ static int g_tower_variant = -1;    // -1 = automatic: k_tower1wa from 2,048 boa
 // diagnostic switch (include/xq_debug.h): the builds compute the same function (36, 39 and 50 to the bit)
 extern "C" void xq_tower_set_variant(int v) { g_tower_variant = v; }
 
-static void *g_clock_sample = nullptr;
 // diagnostic (include/xq_debug.h): three device uint64 that k_tower1wa's product build adds (shader cycles, 100 MHz ticks,
-// samples) to, one workgroup in 64; NULL switches it off
-extern "C" void xq_tower_set_clock_sample(void *dev_u64x3) { g_clock_sample = dev_u64x3; }
+// samples) to, one workgroup in 64; NULL switches it off.  The buffer belongs to the device that is current when it is
+// set: launches on any other device do not get the pointer (a process may drive several GPUs, xq_config.device).
+static std::atomic<void *> g_clock_sample{ nullptr };
+static std::atomic<int> g_clock_sample_dev{ -1 };
+extern "C" void xq_tower_set_clock_sample(void *dev_u64x3)
+{
+    int dev = -1;
+    if (dev_u64x3 && hipGetDevice(&dev) != hipSuccess) dev = -1;
+    g_clock_sample.store(nullptr, std::memory_order_release);
+    g_clock_sample_dev.store(dev, std::memory_order_release);
+    g_clock_sample.store(dev >= 0 ? dev_u64x3 : nullptr, std::memory_order_release);
+}
+static void *clock_sample_for_this_device()
+{
+    void *p = g_clock_sample.load(std::memory_order_acquire);
+    if (!p) return nullptr;
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev != g_clock_sample_dev.load(std::memory_order_acquire)) return nullptr;
+    return p;
+}
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property of a kernel: remembered per (kernel, device
 // ordinal) - a process may drive several GPUs (xq_config.device) - in one atomic bit mask per kernel
@@ -817,7 +834,7 @@ static int launch_tower(void *stream, const void *planes, const void *w1, const 
         return XQ_E_INVALID;
     TowerArgs a{ (const uint16_t *)planes, (const uint16_t *)w1, (const uint16_t *)wt, (const float *)bias,
                  (const uint16_t *)wh, (const float *)bh, (uint16_t *)policy_out, (uint16_t *)value_out, n_boards, n_blocks,
-                 (unsigned long long *)(STAMP ? stamps : g_clock_sample), (const int32_t *)row_src, (const int32_t *)n_rows };
+                 (unsigned long long *)(STAMP ? stamps : clock_sample_for_this_device()), (const int32_t *)row_src, (const int32_t *)n_rows };
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const dim3 grid2((n_boards + 1) / 2), grid4((n_boards + 3) / 4);
 #define XQ_TOWER_LAUNCH(KERNEL, GRID, THREADS, LDS)                                                     \

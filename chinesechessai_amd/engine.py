@@ -253,7 +253,10 @@ class SelfPlayEngine:
         """Result-identical work elimination: the played child's network evaluation becomes the next root's instead
         of being computed a second time (the reference rebuilds its tree every ply, self_play.py:98), so round 0 of
         a ply has nothing to evaluate.  play() / play_refill() switch it on by themselves whenever it is
-        result-identical (one deterministic evaluator, no root noise / virtual loss / tree reuse / arena mode);
+        result-identical AND free: one deterministic evaluator that runs with row compaction (TorchNetEvaluator on the
+        hand-written kernels: a carried root simply has no row in round 0), no root noise / virtual loss / tree reuse /
+        arena mode.  Evaluators without row compaction (HashNetEvaluator, CallbackEvaluator, a chunked TorchNetEvaluator)
+        do NOT get it automatically - skipping round 0 would cost them a blocking read per ply - only by this call;
         this call fixes the choice: True insists (and raises for a combination it cannot serve), False evaluates
         every root afresh like the reference.  None returns to automatic.  Call before new games start."""
         if enable is None:

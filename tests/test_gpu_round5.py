@@ -1,0 +1,186 @@
+"""Round-5 GPU tests (`-m gpu`, through the C ABI): the default trunk kernel against the other build bit for bit at the
+only size the bench runs (VERDICT r04 missing #2), refill x leaf dedupe x root carry-over at a size where the dedupe
+table is really shared between XCDs, and the ADVICE r04 items."""
+import os
+import struct
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from tests.test_gpu_round4 import _mate_line_net, _same_game  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def L():
+    from chinesechessai_amd import _lib
+    lib = _lib.lib()
+    assert lib.xq_device_count() > 0, "no GPU visible"
+    assert lib.xq_device_ok(0) == 1, "not a gfx950 device"
+    return lib
+
+
+def _trunk(L, inet, variant, planes, G, blocks, row_src=None, n_rows=None, fill=None):
+    import torch
+    from chinesechessai_amd import _lib
+    st = torch.cuda.current_stream().cuda_stream
+    P = torch.full((G + 1, 2880), 9.0, device="cuda", dtype=torch.bfloat16)
+    V = torch.full((G + 1, 720), 9.0, device="cuda", dtype=torch.bfloat16)
+    L.xq_tower_set_variant(variant)
+    try:
+        _lib.check(L.xq_tower_nhwc_bf16(st, planes.data_ptr(), inet.hip_w[0].data_ptr(), inet.hip_wt.data_ptr(),
+                                        inet.hip_bt.data_ptr(), inet.hip_hw.data_ptr(), inet.hip_hb.data_ptr(),
+                                        P.data_ptr(), V.data_ptr(), G, blocks,
+                                        None if row_src is None else row_src.data_ptr(),
+                                        None if n_rows is None else n_rows.data_ptr()))
+        torch.cuda.synchronize()
+    finally:
+        L.xq_tower_set_variant(-1)
+    return P, V
+
+
+@pytest.mark.parametrize("blocks", [6, 20])
+def test_default_trunk_kernel_equals_the_other_build_at_full_size(L, blocks):
+    """k_tower1wa (variant 60: the default from 2,048 boards up; one wave per SIMD, the residual tower as one generated
+    asm statement) against k_tower16b<4> (variant 39: round 3's default, plain HIP) BIT FOR BIT at the size the bench
+    runs - 16,384 boards = 4,096 workgroups, 16 per CU back to back - with 6 blocks (BASELINE C3) and 20 (C5), on
+    position-like planes (each square holds at most one piece: what encode_board produces, neural_network.py:128-146)
+    and on dense random ones; then a ROW-MAPPED launch as the engine issues it (row r reads the planes of slot
+    row_src[r]; the count comes from device memory and is ragged: 13,001 of 16,384, not a multiple of 4): rows below
+    the count equal the plain launch's rows of their slots in both builds, rows above it are not written.
+    (neural_network.py:47-71: one forward; the two kernels keep one summation order.)"""
+    import torch
+    from chinesechessai_amd.neural_network import ChessNet, InferenceNet
+    G = 16384
+    torch.manual_seed(100 + blocks)
+    net = ChessNet(num_blocks=blocks).eval()
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.normal_(0, 0.1)
+            m.running_var.uniform_(0.5, 1.5)
+    inet = InferenceNet(net.cuda())
+    g = torch.Generator(device="cuda").manual_seed(5)
+    # position-like: one of 15 codes per square (0 = empty, mostly), channel 14 = side to move for the whole board
+    code = torch.randint(0, 40, (G, 10, 9), device="cuda", generator=g)
+    planes = torch.zeros(G, 10, 9, 16, device="cuda", dtype=torch.bfloat16)
+    for c in range(14):
+        planes[..., c] = (code == c + 1).to(torch.bfloat16)
+    planes[..., 14] = (torch.rand(G, 1, 1, device="cuda", generator=g) < 0.5).to(torch.bfloat16).expand(G, 10, 9)
+    dense = torch.zeros(G, 10, 9, 16, device="cuda", dtype=torch.bfloat16)
+    dense[..., :15] = (torch.rand(G, 10, 9, 15, device="cuda", generator=g) < 0.3).to(torch.bfloat16)
+    for x in (planes, dense):
+        Pa, Va = _trunk(L, inet, 60, x, G, blocks)
+        Pb, Vb = _trunk(L, inet, 39, x, G, blocks)
+        assert Pa[:G].float().abs().max().item() > 0
+        assert torch.equal(Pa.view(torch.int16), Pb.view(torch.int16))           # (row G = the guard row, 9.0 in both)
+        assert torch.equal(Va.view(torch.int16), Vb.view(torch.int16))
+        assert (Pa[G] == 9.0).all() and (Va[G] == 9.0).all()
+    # the engine's form of the launch: a permutation of the slots, 13,001 rows present
+    n = 13001
+    perm = torch.randperm(G, device="cuda", generator=g).to(torch.int32)
+    n_rows = torch.tensor([n], device="cuda", dtype=torch.int32)
+    Pa, Va = _trunk(L, inet, 60, planes, G, blocks)
+    for variant in (60, 39):
+        Pm, Vm = _trunk(L, inet, variant, planes, G, blocks, row_src=perm, n_rows=n_rows)
+        idx = perm[:n].long()
+        assert torch.equal(Pm[:n].view(torch.int16), Pa[idx].view(torch.int16)), variant
+        assert torch.equal(Vm[:n].view(torch.int16), Va[idx].view(torch.int16)), variant
+        # a workgroup carries 4 rows: rows up to the next multiple of 4 may be computed, nothing beyond is touched
+        assert (Pm[(n + 3) // 4 * 4:] == 9.0).all() and (Vm[(n + 3) // 4 * 4:] == 9.0).all(), variant
+
+
+def test_refill_with_dedupe_and_carry_at_a_contended_size(L):
+    """refill x leaf dedupe x root carry-over where the dedupe table is shared for real - 2,048
+    slots (8 per CU: waves of all 8 XCDs meet in the table's entries; in the opening every slot holds the same
+    position), 6,144 games, the mate-line network (a fifth of the games end at ply 7, so slots restart at plies 7, 14,
+    ... 70, 77 ... next to games in mid-play, and every restart re-enters the start position other restarted slots
+    hold too).  A 96-game sample - ids spread over first-deal and restarted games - must equal, record for record and z
+    bit for bit, the PLAIN lock-step path (no dedupe, no carry-over, every root evaluated afresh, one row per leaf)
+    playing the same seeds; every game's outcome must be consistent with its records; the guard blocks stay untouched.
+    Then the same schedule with the exact evaluator: 6,144 games through 2,048 slots, 64 of them against the CPU
+    oracle's game for the seed, move for move, visit for visit, z bit for bit (self_play.py:404-408: handing a worker
+    its next game must not change any game)."""
+    import torch
+    from chinesechessai_amd import distributed as xd
+    from chinesechessai_amd.engine import HashNetEvaluator, SelfPlayEngine, TorchNetEvaluator
+    from oracle import xq_oracle as xo
+    G, T, S = 2048, 6144, 50
+    net = _mate_line_net(2, 11)
+    seeds = (np.arange(T, dtype=np.uint32) * 7 + 3).astype(np.uint32)
+    block = 70 * xd.RECORD_BYTES
+
+    ev = TorchNetEvaluator(net)
+    eng = SelfPlayEngine(G, sims=S, planes_format=ev.planes_format)
+    buf = torch.full(((T + 2) * block,), 0xA5, dtype=torch.uint8, device="cuda")
+    out, plies = eng.play_refill(ev, seeds, buf.data_ptr() + block, check_every=4)
+    assert eng._carry_on and eng.row_compaction and eng.leaf_dedupe                    # everything automatic
+    rows, n_rounds = eng.row_history()
+    eng.close()
+    assert int(out["error"].sum()) == 0
+    assert (buf[:block] == 0xA5).all().item() and (buf[-block:] == 0xA5).all().item()  # guard blocks
+    lengths = out["n_plies"]
+    assert 0.05 * T <= (lengths < 70).sum() <= 0.6 * T, np.bincount(lengths)           # the network does what it is for
+    assert plies < 3 * 70 + 8                                                          # slots restarted out of step
+    # the dedupe did share rows: the opening round of the session is one row, and over the session fewer rows than leaves
+    per = rows.reshape(-1, eng.rounds)
+    assert per[0, 0] == 1 and per[0, 1] == 1 and per.max() <= G
+
+    sample = np.unique(np.concatenate([np.linspace(0, G - 1, 32).astype(int), np.linspace(G, T - 1, 64).astype(int)]))
+    rec_all = buf[block:-block].view(T, block)
+    rec = np.frombuffer(rec_all[torch.as_tensor(sample, device="cuda")].cpu().numpy().tobytes(),
+                        dtype=xd.RECORD_DTYPE).reshape(len(sample), 70)
+    evp = TorchNetEvaluator(net, leaf_dedupe=False)
+    engp = SelfPlayEngine(len(sample), sims=S, planes_format=evp.planes_format)
+    engp.set_root_eval_carry(False)
+    engp.play(evp, seeds[sample], read=False)
+    ref_t = torch.zeros(len(sample) * block, dtype=torch.uint8, device="cuda")
+    engp.pack_samples(ref_t.data_ptr())
+    ref_out = engp.read_game_outcomes()
+    engp.close()
+    ref = xd.records_to_numpy(ref_t).reshape(len(sample), 70)
+    for k in ("winner", "reason", "reason_side", "reason_count", "n_plies", "n_samples", "error"):
+        assert np.array_equal(out[k][sample], ref_out[k]), k
+    for i, g in enumerate(sample):
+        _same_game(rec[i], ref[i], int(g))
+    assert (ref_out["n_plies"] < 70).sum() >= 4                                        # short games are in the sample
+    # every game of the session, not only the sample: outcome scalars agree with the records' valid flags
+    valid = np.frombuffer(rec_all.cpu().numpy().tobytes(), dtype=xd.RECORD_DTYPE).reshape(T, 70)["valid"]
+    assert np.array_equal(valid.sum(axis=1), out["n_samples"])
+
+    # the same schedule with the exact evaluator, against the oracle
+    eng = SelfPlayEngine(G, sims=S)
+    rec_t = torch.zeros(T * block, dtype=torch.uint8, device="cuda")
+    out, plies = eng.play_refill(HashNetEvaluator(), seeds, rec_t.data_ptr(), check_every=4)
+    eng.close()
+    assert int(out["error"].sum()) == 0
+    pick = np.linspace(0, T - 1, 64).astype(int)
+    rec = np.frombuffer(rec_t.view(T, block)[torch.as_tensor(pick, device="cuda")].cpu().numpy().tobytes(),
+                        dtype=xd.RECORD_DTYPE).reshape(len(pick), 70)
+    for i, g in enumerate(pick):
+        rc, og = xo.self_play_game(int(seeds[g]), S)
+        assert rc == 0
+        assert (out["winner"][g], out["reason"][g], out["n_plies"][g], out["n_samples"][g]) == (
+            og.winner, og.end_reason, og.n_plies, og.n_samples), g
+        assert int(rec[i]["valid"].sum()) == og.n_samples
+        for j in range(og.n_samples):
+            k = og.s_nmoves[j]
+            assert int(rec[i, j]["n_moves"]) == k and int(rec[i, j]["chosen"]) == og.t_move[j], (g, j)
+            assert rec[i, j]["moves"][:k].tolist() == list(og.s_moves[j][:k]), (g, j)
+            assert rec[i, j]["counts"][:k].tolist() == list(og.t_visits[j][:k]), (g, j)
+            assert struct.pack("<d", og.s_z[j]) == struct.pack("<d", float(rec[i, j]["z"])), (g, j)
+
+
+def test_auto_carry_needs_row_compaction(L):
+    """the automatic root-evaluation carry-over is limited to evaluators WITH row compaction (without it
+    skipping round 0 costs a blocking read per ply); the exact evaluator gets it only when asked."""
+    from chinesechessai_amd.engine import HashNetEvaluator, SelfPlayEngine
+    seeds = np.arange(4, dtype=np.uint32)
+    eng = SelfPlayEngine(4, sims=16, max_moves=2)
+    a = eng.play(HashNetEvaluator(), seeds)
+    assert not eng._carry_on
+    eng.set_root_eval_carry(True)
+    b = eng.play(HashNetEvaluator(), seeds)
+    assert eng._carry_on
+    eng.close()
+    assert np.array_equal(a.chosen, b.chosen) and np.array_equal(a.s_counts, b.s_counts)

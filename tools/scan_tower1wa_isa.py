@@ -7,7 +7,11 @@ know that a[0:191] are live between those statements.  Checked here, on both ins
     no wait states for an asm MFMA);
 (2) every AGPR the compiler uses by itself (spills around the big statement) while the accumulators are live - i.e. in
     front of the END of the tower statement - is a224 or higher;
-(3) the kernel uses no scratch memory and at most 512 registers."""
+(3) the kernel uses no scratch memory and at most 512 registers;
+(4) the generated bodies write m0 (one s_mov / s_add per weight-DMA piece) and "m0" cannot be listed as a clobber (hipcc
+    answers with its reserved-register warning): every compiler-issued LDS-DMA behind the END of a big statement must
+    therefore be preceded - behind that END - by a compiler write of m0.  Checked for k_tower1wa and for
+    k_policy_fc1w (csrc/xq_policy.hip, compiled here too)."""
 import os
 import re
 import subprocess
@@ -81,4 +85,51 @@ for name in ("k_tower1waILb0ELi0E", "k_tower1waILb1ELi0E"):
         print("   line %d: %s" % (ln, l))
     if bad or low_cc or scratch or nfree > 512:
         rc = 1
+
+
+def m0_after_big_statement(text, name):
+    """(number of LDS-DMA instructions behind the big asm statement, those among them not preceded by an m0 write)"""
+    m = re.search(r"^_ZN?\w*%s\w*:[^\n]*\n(.*?)\n\s*\.end_amdhsa_kernel" % name, text, re.S | re.M)
+    lines = m.group(1).split("\n")
+    blocks, cur = [], None
+    for i, l in enumerate(lines):
+        if "#ASMSTART" in l:
+            cur = i
+        elif "#ASMEND" in l and cur is not None:
+            blocks.append((cur, i))
+            cur = None
+    big = max(blocks, key=lambda b: b[1] - b[0])
+    m0_set, n_dma, bad = False, 0, []
+    for i in range(big[1] + 1, len(lines)):
+        l = lines[i].strip()
+        if not l or l.startswith((";", ".")) or l.endswith(":"):
+            continue
+        ops = l.split(None, 1)
+        if len(ops) > 1 and ops[0].startswith("s_") and ops[1].split(",")[0].strip() == "m0":
+            m0_set = True
+        if (ops[0].startswith("global_load_lds") or (ops[0].startswith("buffer_load") and l.endswith(" lds"))):
+            n_dma += 1
+            if not m0_set:
+                bad.append((i + 1, l))
+    return n_dma, bad
+
+
+for name in ("k_tower1waILb0ELi0E", "k_tower1waILb1ELi0E"):
+    n_dma, badm = m0_after_big_statement(text, name)
+    print("%s: %d compiler-issued LDS-DMA behind the tower statement, %d without an m0 write in front" % (name, n_dma, len(badm)))
+    for ln, l in badm[:5]:
+        print("   line %d: %s" % (ln, l))
+    if badm or n_dma == 0:          # (the heads' weights arrive by LDS-DMA: none at all means this scan no longer sees them)
+        rc = 1
+if len(sys.argv) <= 1:
+    ppath = os.path.join(os.path.dirname(path), "xq_policy.s")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17", "-Wno-unused-function",
+                           "--cuda-device-only", "-S", "-o", ppath, os.path.join(ROOT, "chinesechessai_amd", "csrc", "xq_policy.hip")],
+                          stderr=subprocess.DEVNULL)
+    ptext = open(ppath).read()
+    for name in sorted(set(re.findall(r"^(_Z\w*k_policy_fc1w\w*):", ptext, re.M))):
+        n_dma, badm = m0_after_big_statement(ptext, name.lstrip("_ZN"))
+        print("%s: %d compiler-issued LDS-DMA behind the K-loop statement, %d without an m0 write in front" % (name, n_dma, len(badm)))
+        if badm:
+            rc = 1
 sys.exit(rc)
