@@ -13,7 +13,7 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libxq_hip.so")
 SOURCES = [os.path.join(CSRC, "xq_engine.hip"), os.path.join(CSRC, "xq_conv.hip"), os.path.join(CSRC, "xq_replay.hip"),
            os.path.join(CSRC, "xq_tower.hip"), os.path.join(CSRC, "xq_policy.hip")]
-HEADERS = [os.path.join(CSRC, "xq_device.hpp"), os.path.join(CSRC, "xq_mfma.hpp"), os.path.join(CSRC, "xq_tower_probes.hpp"),
+HEADERS = [os.path.join(CSRC, "xq_device.hpp"), os.path.join(CSRC, "xq_attack.hpp"), os.path.join(CSRC, "xq_mfma.hpp"), os.path.join(CSRC, "xq_tower_probes.hpp"),
            os.path.join(CSRC, "xq_tower1wa.hpp"), os.path.join(CSRC, "xq_tower1wa_body.inc"), os.path.join(CSRC, "xq_policy_fc1w_body.inc"),
            os.path.join(_HERE, "..", "include", "xq_selfplay.h"), os.path.join(_HERE, "..", "include", "xq_debug.h")]
 
@@ -49,10 +49,20 @@ def hipcc_path():
 
 def build(force=False, verbose=False):
     """Cross-compile the HIP library for gfx950 in-tree (works without a GPU)."""
-    deps = SOURCES + HEADERS
+    headers = list(HEADERS)
     # XQ_TOWER_PROBES=1 in the environment also compiles csrc/xq_tower_probes.hpp: the trunk kernel's experiments and timing
     # probes (tools/bench_tower.py, tools/probe_tiles.py, tools/probe_loop.py); the default library leaves them out
     probes = os.environ.get("XQ_TOWER_PROBES", "0") == "1"
+    if probes:
+        # the timing-only bodies of the two generated asm statements are not committed: written when missing or older than
+        # their generator, and dependencies of the objects like every other header
+        tools = os.path.join(os.path.dirname(os.path.dirname(CSRC)), "tools")
+        for gen, inc in (("gen_tower1wa.py", "xq_tower1wa_abl.inc"), ("gen_policy_fc1w.py", "xq_policy_fc1w_abl.inc")):
+            gp, ip = os.path.join(tools, gen), os.path.join(CSRC, inc)
+            if not os.path.exists(ip) or os.path.getmtime(ip) < os.path.getmtime(gp):
+                subprocess.check_call([sys.executable, gp, "--ablations"], stdout=subprocess.DEVNULL)
+            headers.append(ip)
+    deps = SOURCES + headers
     flagfile = os.path.join(CSRC, "build", "flags.txt")
     built_with = open(flagfile).read().strip() if os.path.exists(flagfile) else ""
     if probes and built_with != "probes":
@@ -64,16 +74,12 @@ def build(force=False, verbose=False):
     flags = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
     if probes:
         flags.append("-DXQ_TOWER_PROBES=1")
-        # the timing-only bodies of the two generated asm statements are not committed: write them first
-        tools = os.path.join(os.path.dirname(os.path.dirname(CSRC)), "tools")
-        for gen in ("gen_tower1wa.py", "gen_policy_fc1w.py"):
-            subprocess.check_call([sys.executable, os.path.join(tools, gen), "--ablations"], stdout=subprocess.DEVNULL)
     objdir = os.path.join(CSRC, "build")
     os.makedirs(objdir, exist_ok=True)
     jobs, tower_rebuilt = [], False
     for src in SOURCES:
         obj = os.path.join(objdir, os.path.basename(src) + ".o")
-        if force or not os.path.exists(obj) or any(os.path.getmtime(obj) < os.path.getmtime(d) for d in [src] + HEADERS):
+        if force or not os.path.exists(obj) or any(os.path.getmtime(obj) < os.path.getmtime(d) for d in [src] + headers):
             tower_rebuilt = tower_rebuilt or src.endswith("xq_tower.hip")
             cmd = [hipcc_path()] + flags + ["-c", "-o", obj, src]
             if verbose:

@@ -12,6 +12,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "xq_attack.hpp"
 
 namespace xq {
 
@@ -70,7 +71,7 @@ __device__ __forceinline__ int cm_index(int s) { return (s % 9) * 10 + s / 9; }
 
 // Wave-uniform view of a board held in LDS (all fields identical in every lane).
 struct BoardView {
-    BB occ, occC;        // occupancy row-major / column-major
+    BB occ;              // occupancy, row-major
     BB red, blk;         // piece sets by colour (row-major)
     int pA, pB;          // per lane: piece on square lane, and on square 64+lane (lane < 26)
 };
@@ -84,10 +85,6 @@ __device__ __forceinline__ BoardView load_view(const int8_t *bd)
     v.occ.lo = __ballot(v.pA != 0);  v.occ.hi = __ballot(v.pB != 0);
     v.red.lo = __ballot(v.pA > 0);   v.red.hi = __ballot(v.pB > 0);
     v.blk.lo = __ballot(v.pA < 0);   v.blk.hi = __ballot(v.pB < 0);
-    int qA = bd[(lane % 10) * 9 + lane / 10];
-    int s2 = 64 + lane;
-    int qB = (lane < 26) ? bd[(s2 % 10) * 9 + s2 / 10] : 0;
-    v.occC.lo = __ballot(qA != 0);   v.occC.hi = __ballot(qB != 0);
     return v;
 }
 
@@ -103,81 +100,53 @@ __device__ __forceinline__ bool in_palace(int X, int r, int c)
     return (X == 1 ? (r >= 7 && r <= 9) : (r >= 0 && r <= 2)) && c >= 3 && c <= 5;
 }
 
-// Does the piece of type `et` on square `es` (both wave-uniform), moving by the generator rules
-// of side X (chess_env.py:127,143,159,240 key on current_player — Appendix A1), have the
-// square k (per lane) among its pseudo-moves on the occupancy (rm, cm) (per lane)?
-__device__ __forceinline__ bool attacks(int et, int es, int k, const BB &rm, const BB &cm, int X)
+// The per-row / per-column bit masks of xq_attack.hpp for the board of view `v`, attackers = the pieces of colour `att`:
+// lane = square, one ds_or_b32 per table a piece belongs to (LDS atomics of one wave execute in issue order; the
+// tables are wave-private).  Returns the rows that hold attacker kings / advisors / bishops (bit r + 2, wave-uniform):
+// xq_attack.hpp's `kab` is a range test on it.
+__device__ __forceinline__ uint32_t build_attack_maps(AttackMaps &M, const BoardView &v, int att)
 {
-    const int er = es / 9, ec = es % 9, kr = k / 9, kc = k % 9;
-    const int dr = kr - er, dc = kc - ec;
-    const int adr = dr < 0 ? -dr : dr, adc = dc < 0 ? -dc : dc;
-    switch (et) {
-    case ROOK:
-    case CANNON: {
-        if (es == k) return false;
-        int n;
-        if (dr == 0) {
-            int lo = ec < kc ? ec : kc, hi = ec < kc ? kc : ec;
-            n = __builtin_popcount(row_bits(rm, kr) & (((1u << (hi - lo - 1)) - 1u) << (lo + 1)));
-        } else if (dc == 0) {
-            int lo = er < kr ? er : kr, hi = er < kr ? kr : er;
-            n = __builtin_popcount(col_bits(cm, kc) & (((1u << (hi - lo - 1)) - 1u) << (lo + 1)));
-        } else return false;
-        if (et == ROOK) return n == 0;
-        // cannon (chess_env.py:215-235): an empty k is reached only before the screen; an
-        // occupied k only as the first piece behind the screen
-        return bb_test(rm, k) ? (n == 1) : (n == 0);
+    const int lane = XQ_LANE;
+    uint32_t *w = reinterpret_cast<uint32_t *>(&M);
+    w[lane] = 0u;
+    if (lane < ATTACK_MAP_DWORDS - 64) w[64 + lane] = 0u;
+    wave_sync();
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const int p = h ? v.pB : v.pA;
+        if (p != 0) {
+            const int s = lane + 64 * h, r = (s * 57) >> 9, c = s - 9 * r;
+            atomicOr(&M.occrow[r + 2], 4u << c);
+            atomicOr(&M.occcol[c], 1u << r);
+            if ((p ^ att) >= 0) {                                    // a piece of the attackers' colour
+                const int T = p < 0 ? -p : p, sh = attack_type_shift(T);
+                atomicOr(&w[attack_row_table(T) + r + 2], (4u << c) << sh);
+                if (T == ROOK || T == CANNON) atomicOr(&M.rc_col[c], (1u << r) << sh);
+            }
+        }
     }
-    case KNIGHT: {
-        int leg;
-        if (adr == 2 && adc == 1) leg = (er + dr / 2) * 9 + ec;
-        else if (adr == 1 && adc == 2) leg = er * 9 + ec + dc / 2;
-        else return false;
-        return !bb_test(rm, leg);
-    }
-    case PAWN: {
-        int fwd = (X == 1) ? -1 : 1;
-        bool crossed = (X == 1) ? (er < 5) : (er >= 5);
-        return (dr == fwd && dc == 0) || (crossed && dr == 0 && adc == 1);
-    }
-    case KING:
-        return (adr + adc == 1) && in_palace(X, kr, kc);
-    case ADVISOR:
-        return (adr == 1 && adc == 1) && in_palace(X, kr, kc);
-    case BISHOP: {
-        if (!(adr == 2 && adc == 2)) return false;
-        if (X == 1 ? (kr < 5) : (kr >= 4)) return false;        // chess_env.py:159-170 (river 5 / 4)
-        return !bb_test(rm, (er + dr / 2) * 9 + ec + dc / 2);
-    }
-    default:
-        return false;
-    }
+    wave_sync();
+    const uint32_t kab = lane < 14 ? (M.ka_row[lane] | M.b_row[lane]) : 0u;
+    return (uint32_t)__ballot(kab != 0u);
 }
 
-// chess_env.py:506-548 restated as an attack test: is square k attacked by any piece of the
-// set `att` (wave-uniform bitboard over the ORIGINAL board `v`), on the per-lane occupancy
-// (rm, cm), skipping the piece on `skip` (captured by the candidate move), under rules X?
-__device__ __forceinline__ bool attacked_by(const BoardView &v, const BB &att, int k, int skip,
-                                            const BB &rm, const BB &cm, int X)
+// attacker kings / advisors / bishops anywhere in rows lo - 2 .. hi + 2 ?
+__device__ __forceinline__ bool kab_in_rows(uint32_t kab_rows, int lo, int hi)
 {
-    bool hit = false;
-    for (uint64_t m = att.lo; m; m &= m - 1) {
-        int es = uni(__builtin_ctzll(m));
-        int et = __builtin_amdgcn_readlane(v.pA, es);
-        et = et < 0 ? -et : et;
-        hit |= (es != skip) && attacks(et, es, k, rm, cm, X);
-    }
-    for (uint64_t m = att.hi; m; m &= m - 1) {
-        int b = uni(__builtin_ctzll(m));
-        int et = __builtin_amdgcn_readlane(v.pB, b);
-        et = et < 0 ? -et : et;
-        hit |= (64 + b != skip) && attacks(et, 64 + b, k, rm, cm, X);
-    }
-    return hit;
+    return ((kab_rows >> lo) & ((1u << (hi - lo + 5)) - 1u)) != 0u;
 }
 
-// chess_env.py:466-495 on cached king squares
-__device__ __forceinline__ bool kings_facing(int rk, int bk, const BB &cm)
+// _is_in_check (chess_env.py:506-548) of the king cached on square k (wave-uniform) against the maps' attackers,
+// evaluated with self.current_player == X
+__device__ __forceinline__ bool in_check(const AttackMaps &M, uint32_t kab_rows, int k, int X)
+{
+    if (k < 0) return false;
+    const int kr = (k * 57) >> 9;
+    return king_attacked<false>(M, k, 0, 0, X, -1, kab_in_rows(kab_rows, kr, kr));
+}
+
+// chess_env.py:466-495 on cached king squares, on the board the maps were built from
+__device__ __forceinline__ bool kings_facing(const AttackMaps &M, int rk, int bk)
 {
     if (rk < 0 || bk < 0) return false;
     int rc = rk % 9, bc = bk % 9;
@@ -185,16 +154,7 @@ __device__ __forceinline__ bool kings_facing(int rk, int bk, const BB &cm)
     int rr = rk / 9, br = bk / 9;
     int lo = rr < br ? rr : br, hi = rr < br ? br : rr;
     if (hi - lo < 1) return true;          // same square: empty range -> "facing" (as the reference)
-    return (col_bits(cm, rc) & (((1u << (hi - lo - 1)) - 1u) << (lo + 1))) == 0;
-}
-
-// _is_in_check(player) evaluated with self.current_player == X (wave-uniform result)
-__device__ __forceinline__ bool in_check(const BoardView &v, int player, int X, int rk, int bk)
-{
-    int k = (player == 1) ? rk : bk;
-    if (k < 0) return false;
-    const BB &att = (player == 1) ? v.blk : v.red;
-    return attacked_by(v, att, k, -1, v.occ, v.occC, X);
+    return (M.occcol[rc] & (((1u << (hi - lo - 1)) - 1u) << (lo + 1))) == 0;
 }
 
 // ---------------------------------------------------------------- wave scan helper
@@ -213,13 +173,13 @@ __device__ __forceinline__ int wave_incl_scan(int x)
 // chess_env.py:76-121.  Output order is part of the contract: own pieces in row-major square
 // order, per piece the generator's emission order, filters keep order.
 // Lane mapping for candidates: lane = (own piece index & 15) * 4 + direction slot.
-// cand / out: LDS u16[128]; own_sq: LDS u8[32].  Returns the (wave-uniform) number of legal moves.
-__device__ int wave_movegen(const int8_t *bd, const BoardView &v, int side, int rk, int bk,
+// cand / out: LDS u16[128]; own_sq: LDS u8[32].  M / kab_rows: build_attack_maps(M, v, -side) of this board.
+// Returns the (wave-uniform) number of legal moves.
+__device__ int wave_movegen(const int8_t *bd, const BoardView &v, const AttackMaps &M, uint32_t kab_rows, int side, int rk, int bk,
                             uint16_t *cand, uint16_t *out, uint8_t *own_sq)
 {
     const int lane = XQ_LANE;
     const BB &own = (side == 1) ? v.red : v.blk;
-    const BB &ene = (side == 1) ? v.blk : v.red;
     const int n_lo = __builtin_popcountll(own.lo);
     const int n_own = n_lo + __builtin_popcountll(own.hi);
 
@@ -247,7 +207,7 @@ __device__ int wave_movegen(const int8_t *bd, const BoardView &v, int side, int 
             if (tp == ROOK || tp == CANNON) {
                 // ray order right, left, down, up (chess_env.py:203,218)
                 const bool horiz = d < 2, fwd = (d & 1) == 0;
-                const uint32_t line = horiz ? row_bits(v.occ, r) : col_bits(v.occC, c);
+                const uint32_t line = horiz ? M.occrow[r + 2] >> 2 : M.occcol[c];
                 const int p = horiz ? c : r, len = horiz ? 9 : 10;
                 delta = horiz ? (fwd ? 1 : -1) : (fwd ? 9 : -9);
                 int n_empty, blk = -1, cap = -1;
@@ -332,7 +292,13 @@ __device__ int wave_movegen(const int8_t *bd, const BoardView &v, int side, int 
     if (n_cand > MAXM) n_cand = MAXM;
     wave_sync();
 
-    // suicide filter (chess_env.py:431-464): apply on a private occupancy, test the own king
+    // suicide filter (chess_env.py:431-464): the own king's square after the move (only a moving king moves it, A5)
+    // must not be attacked on the occupancy the move leaves behind, nor face the other king's cached square
+    const int K = (side == 1) ? rk : bk, O = (side == 1) ? bk : rk;
+    // rows a tested king square can lie in: the cached one, and the palace rows a king move can reach
+    int lo = (side == 1) ? 7 : 0, hi = lo + 2;
+    if (K >= 0) { const int kr = (K * 57) >> 9; lo = kr < lo ? kr : lo; hi = kr > hi ? kr : hi; }
+    const bool kab = kab_in_rows(kab_rows, lo, hi);
     int n_out = 0;
     for (int base = 0; base < n_cand; base += 64) {
         const int j = base + lane;
@@ -340,18 +306,9 @@ __device__ int wave_movegen(const int8_t *bd, const BoardView &v, int side, int 
         int mv = 0;
         if (j < n_cand) {
             mv = cand[j];
-            const int f = mv / 90, t = mv % 90;
-            const int P = bd[f];
-            BB rm = v.occ, cm = v.occC;
-            bb_clear(rm, f); bb_set(rm, t);
-            bb_clear(cm, cm_index(f)); bb_set(cm, cm_index(t));
-            const int rk2 = (P == KING) ? t : rk, bk2 = (P == -KING) ? t : bk;   // only a moving king (A5)
-            const int k = (side == 1) ? rk2 : bk2;
-            bool bad = false;
-            if (k >= 0) bad = attacked_by(v, ene, k, t, rm, cm, side);
-            legal = !(bad || kings_facing(rk2, bk2, cm));
-        } else {
-            // keep the uniform loops of attacked_by convergent: nothing to do for idle lanes
+            const int f = mv / 90, t = mv - 90 * f;
+            const int k = (bd[f] == side) ? t : K;                   // +-KING == +-1 == side
+            legal = !king_attacked<true>(M, k, f, t, side, O, kab);
         }
         const uint64_t mask = __ballot(legal);
         if (legal) out[n_out + __builtin_popcountll(mask & ((1ull << lane) - 1ull))] = (uint16_t)mv;
@@ -465,7 +422,7 @@ struct MoveResult {
 // The board in LDS is updated in place; `legal` receives the legal moves of the NEW side to move
 // when the game is not over by king capture (they double as the next position's move list).
 template <bool WANT_REWARD, bool WANT_CHECK, class Hist>
-__device__ MoveResult wave_make_move(int8_t *bd, MState &s, int move, Hist &hist,
+__device__ MoveResult wave_make_move(int8_t *bd, MState &s, int move, Hist &hist, AttackMaps &M,
                                      uint16_t *cand, uint16_t *legal, uint8_t *own_sq)
 {
     const int lane = XQ_LANE;
@@ -493,8 +450,11 @@ __device__ MoveResult wave_make_move(int8_t *bd, MState &s, int move, Hist &hist
     }
 
     BoardView v = load_view(bd);
+    // every attack question of this move has the mover's pieces as the attackers: the check it gives (:317), the
+    // next side's suicide filter (:431-464) and that side's in-check test (:625,641) - one set of maps
+    const uint32_t kab_rows = build_attack_maps(M, v, s.side);
     int is_checking = 0;
-    if (WANT_CHECK) is_checking = in_check(v, -s.side, s.side, s.rk, s.bk) ? 1 : 0;   // :317
+    if (WANT_CHECK) is_checking = uni(in_check(M, kab_rows, s.side == 1 ? s.bk : s.rk, s.side) ? 1 : 0);   // :317
     res.is_check = is_checking;
     if (!res.done && is_checking) {                                                // :318-327
         if (WANT_REWARD) {
@@ -519,9 +479,9 @@ __device__ MoveResult wave_make_move(int8_t *bd, MState &s, int move, Hist &hist
     s.move_count += 1;
 
     if (!res.done) {                                                               // :352-397
-        const int nl = wave_movegen(bd, v, s.side, s.rk, s.bk, cand, legal, own_sq);
+        const int nl = wave_movegen(bd, v, M, kab_rows, s.side, s.rk, s.bk, cand, legal, own_sq);
         res.n_legal = nl;
-        const bool in_chk = (nl == 0) ? in_check(v, s.side, s.side, s.rk, s.bk) : false;
+        const bool in_chk = (nl == 0) ? uni(in_check(M, kab_rows, s.side == 1 ? s.rk : s.bk, s.side) ? 1 : 0) != 0 : false;
         if (nl == 0 && in_chk) {                                                   // :354-359
             res.done = 1; res.reward = 200; s.winner = -s.side;
             s.reason = R_CHECKMATE; s.reason_side = s.side;

@@ -116,6 +116,7 @@ struct __align__(16) WaveLds {
     uint16_t cand[128];
     uint16_t legal[128];
     uint8_t  own_sq[32];
+    AttackMaps maps;         // per-row / per-column piece masks of the position being generated (xq_attack.hpp)
     uint16_t path_node[PATH_CAP];
     uint16_t path_move[PATH_CAP];
     uint64_t path_key[PATH_CAP];
@@ -445,7 +446,8 @@ __device__ void new_game(const Eng &E, int g, WaveLds &L)
     wave_sync();
     BoardView v = load_view(L.bd);
     const int rk = 9 * 9 + 4, bk = 4;
-    const int n = wave_movegen(L.bd, v, 1, rk, bk, L.cand, L.legal, L.own_sq);
+    const uint32_t kab = build_attack_maps(L.maps, v, -1);
+    const int n = wave_movegen(L.bd, v, L.maps, kab, 1, rk, bk, L.cand, L.legal, L.own_sq);
     for (int j = lane; j < n; j += 64) E.root_moves[(size_t)g * MAXM + j] = L.legal[j];
     if (lane < 12) E.board[(size_t)g * 12 + lane] = pack_dword(L.bd, lane);
     GameS gs;
@@ -477,7 +479,8 @@ __global__ __launch_bounds__(64) void k_set_roots(Eng E, const int8_t *boards, c
     const int32_t *st = state + (size_t)g * XQ_STATE_WORDS;
     BoardView v = load_view(L.bd);
     const int side = st[XQ_S_PLAYER], rk = st[XQ_S_RED_KING], bk = st[XQ_S_BLACK_KING];
-    const int n = wave_movegen(L.bd, v, side, rk, bk, L.cand, L.legal, L.own_sq);
+    const uint32_t kab = build_attack_maps(L.maps, v, -side);
+    const int n = wave_movegen(L.bd, v, L.maps, kab, side, rk, bk, L.cand, L.legal, L.own_sq);
     for (int j = lane; j < n; j += 64) E.root_moves[(size_t)g * MAXM + j] = L.legal[j];
     if (lane < 12) E.board[(size_t)g * 12 + lane] = pack_dword(L.bd, lane);
     GameS gs;
@@ -699,9 +702,9 @@ __global__ __launch_bounds__(64, OCC) void k_search_round(Eng E, int round, int 
             }
             MoveResult mr;
             if (E.want_check)
-                mr = wave_make_move<false, true>(L.bd, st, L.path_move[depth - 1], hist, L.cand, L.legal, L.own_sq);
+                mr = wave_make_move<false, true>(L.bd, st, L.path_move[depth - 1], hist, L.maps, L.cand, L.legal, L.own_sq);
             else
-                mr = wave_make_move<false, false>(L.bd, st, L.path_move[depth - 1], hist, L.cand, L.legal, L.own_sq);
+                mr = wave_make_move<false, false>(L.bd, st, L.path_move[depth - 1], hist, L.maps, L.cand, L.legal, L.own_sq);
             flags |= mr.is_check ? F_CHECK : 0;
             const bool terminal = (mr.n_legal == 0) || (st.winner != WINNER_NONE);     // self_play.py:126
             if (!terminal) {
@@ -958,7 +961,7 @@ __global__ __launch_bounds__(64) void k_play_move(Eng E)
 
     MState st = to_mstate(gs);
     HistGlobal hist{ E.pos_hist + (size_t)g * PATH_CAP, E.chk_hist + (size_t)g * PATH_CAP, gs.n_hist, gs.n_hist, 0ull, 0 };
-    MoveResult mr = wave_make_move<true, true>(L.bd, st, move, hist, L.cand, L.legal, L.own_sq);
+    MoveResult mr = wave_make_move<true, true>(L.bd, st, move, hist, L.maps, L.cand, L.legal, L.own_sq);
     from_mstate(gs, st);
     if (lane == 0) {
         if (gs.n_hist < PATH_CAP) {
@@ -1135,7 +1138,8 @@ __global__ __launch_bounds__(64) void k_rules_legal(int n, const int8_t *boards,
     for (int s = lane; s < 96; s += 64) L.bd[s] = s < 90 ? boards[(size_t)g * 90 + s] : 0;
     wave_sync();
     BoardView v = load_view(L.bd);
-    const int cnt = wave_movegen(L.bd, v, player[g], rk[g], bk[g], L.cand, L.legal, L.own_sq);
+    const uint32_t kab = build_attack_maps(L.maps, v, -player[g]);
+    const int cnt = wave_movegen(L.bd, v, L.maps, kab, player[g], rk[g], bk[g], L.cand, L.legal, L.own_sq);
     for (int j = lane; j < cnt; j += 64) moves[(size_t)g * MAXM + j] = L.legal[j];
     if (lane == 0) counts[g] = cnt;
 }
@@ -1155,7 +1159,8 @@ __global__ __launch_bounds__(64) void k_rules_threats(int n, const int8_t *board
     wave_sync();
     BoardView v = load_view(L.bd);
     const int p = side[g];
-    const int cnt = wave_movegen(L.bd, v, p, rk[g], bk[g], L.cand, L.legal, L.own_sq);
+    const uint32_t kab = build_attack_maps(L.maps, v, -p);
+    const int cnt = wave_movegen(L.bd, v, L.maps, kab, p, rk[g], bk[g], L.cand, L.legal, L.own_sq);
     int base = 0;
     for (int j0 = 0; j0 < cnt; j0 += 64) {
         const int j = j0 + lane;
@@ -1193,9 +1198,11 @@ __global__ __launch_bounds__(64) void k_rules_query(int n, const int8_t *boards,
     for (int s = lane; s < 96; s += 64) L.bd[s] = s < 90 ? boards[(size_t)g * 90 + s] : 0;
     wave_sync();
     BoardView v = load_view(L.bd);
-    const bool cr = in_check(v, 1, player[g], rk[g], bk[g]);
-    const bool cb = in_check(v, -1, player[g], rk[g], bk[g]);
-    const bool f = kings_facing(rk[g], bk[g], v.occC);
+    uint32_t kab = build_attack_maps(L.maps, v, -1);
+    const bool cr = in_check(L.maps, kab, rk[g], player[g]);
+    const bool f = kings_facing(L.maps, rk[g], bk[g]);
+    kab = build_attack_maps(L.maps, v, 1);
+    const bool cb = in_check(L.maps, kab, bk[g], player[g]);
     if (lane == 0) { chk_red[g] = cr; chk_black[g] = cb; facing[g] = f; }
 }
 
@@ -1216,7 +1223,7 @@ __global__ __launch_bounds__(64) void k_rules_make_move(int n, int8_t *boards, i
     st.cchk = sw[XQ_S_CONSEC_CHECKS]; st.reason = sw[XQ_S_REASON]; st.reason_side = sw[XQ_S_REASON_SIDE];
     st.reason_count = sw[XQ_S_REASON_COUNT];
     HistGlobal hist{ pos_hist + (size_t)g * stride, chk_hist + (size_t)g * stride, n_hist[g], n_chk[g], 0ull, 0 };
-    MoveResult mr = wave_make_move<true, true>(L.bd, st, move[g], hist, L.cand, L.legal, L.own_sq);
+    MoveResult mr = wave_make_move<true, true>(L.bd, st, move[g], hist, L.maps, L.cand, L.legal, L.own_sq);
     wave_sync();
     for (int s = lane; s < 90; s += 64) boards[(size_t)g * 90 + s] = L.bd[s];
     for (int j = lane; j < mr.n_legal; j += 64) next_moves[(size_t)g * MAXM + j] = L.legal[j];
@@ -1859,10 +1866,12 @@ extern "C" int xq_engine_search_round(xq_engine *e, int round, int eval_kind, co
                                                     round, batch, eval_kind, ev_a, ev_v, planes, fmt)
     if (e->E.vloss) XQ_LAUNCH_SEARCH(4, true);
     else switch (g_search_occ) {
+#if XQ_TOWER_PROBES                 // the other register budgets spill 27-58 VGPRs: comparison builds, probes library only
     case 3: XQ_LAUNCH_SEARCH(3, false); break;
     case 5: XQ_LAUNCH_SEARCH(5, false); break;
     case 6: XQ_LAUNCH_SEARCH(6, false); break;
     case 8: XQ_LAUNCH_SEARCH(8, false); break;
+#endif
     default: XQ_LAUNCH_SEARCH(4, false); break;
     }
 #undef XQ_LAUNCH_SEARCH
