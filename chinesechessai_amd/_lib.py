@@ -203,6 +203,7 @@ _DEBUG_SIGNATURES = {
     "xq_conv3x3_set_variant": (None, [C.c_int]),
     "xq_conv3x3_debug_stamps": (C.c_int, [C.c_int, C.c_int] + [C.c_void_p] * 6 + [C.c_int, C.c_int, C.c_void_p]),
     "xq_engine_set_search_occupancy": (None, [C.c_int]),
+    "xq_engine_set_search_stamps": (C.c_int, [C.c_void_p]),
     "xq_policy_fc_set_variant": (None, [C.c_int]),
     "xq_policy_fc_debug_stamps": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "xq_policy_fc_debug": (C.c_int, [C.c_int] + [C.c_void_p] * 5 + [C.c_int, C.c_int, C.c_int]),

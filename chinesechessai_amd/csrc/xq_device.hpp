@@ -320,17 +320,18 @@ __device__ int wave_movegen(const int8_t *bd, const BoardView &v, const AttackMa
 
 // ---------------------------------------------------------------- board packing (HBM form)
 // 4 bits per square: 0 empty, 1..7 red K,A,B,N,R,C,P, 8..14 black; 12 dwords = 48 B per board.
-__device__ __forceinline__ uint32_t pack_dword(const int8_t *bd, int i)      // squares 8i..8i+7
+// The LDS board is 96 bytes (squares 90..95 hold 0) and 8-byte aligned: one ds_read_b64 per lane, four squares per SWAR step.
+__device__ __forceinline__ uint32_t nibbles4(uint32_t w)         // 4 signed bytes (0, +-1..7) -> 4 nibble codes
 {
-    uint32_t w = 0;
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-        int s = 8 * i + j;
-        int p = (s < 90) ? bd[s] : 0;
-        uint32_t code = p > 0 ? (uint32_t)p : (p < 0 ? (uint32_t)(7 - p) : 0u);
-        w |= code << (4 * j);
-    }
-    return w;
+    const uint32_t n = (w >> 7) & 0x01010101u;                    // 1 where the byte is negative
+    uint32_t x = ((w ^ (n * 0xFFu)) & 0x07070707u) | (n << 3);    // p > 0: p;  p < 0: 8 + (~p & 7) = 7 - p
+    x = (x | (x >> 4)) & 0x00FF00FFu;
+    return (x | (x >> 8)) & 0x0000FFFFu;
+}
+__device__ __forceinline__ uint32_t pack_dword(const int8_t *bd, int i)      // squares 8i..8i+7, i < 12
+{
+    const uint2 v = *reinterpret_cast<const uint2 *>(bd + 8 * i);
+    return nibbles4(v.x) | (nibbles4(v.y) << 16);
 }
 
 __device__ __forceinline__ void unpack_to_lds(const uint32_t *packed, int8_t *bd)
@@ -421,9 +422,14 @@ struct MoveResult {
 //
 // The board in LDS is updated in place; `legal` receives the legal moves of the NEW side to move
 // when the game is not over by king capture (they double as the next position's move list).
-template <bool WANT_REWARD, bool WANT_CHECK, class Hist>
+//
+// `hook(bd)` runs once, wave-convergent, as soon as the board holds the new position - before the check test and the
+// move generation: the search kernel uses it to send the leaf's board, planes and table look on their way early.
+struct NoHook { __device__ void operator()(const int8_t *) const {} };
+
+template <bool WANT_REWARD, bool WANT_CHECK, class Hist, class Hook = NoHook>
 __device__ MoveResult wave_make_move(int8_t *bd, MState &s, int move, Hist &hist, AttackMaps &M,
-                                     uint16_t *cand, uint16_t *legal, uint8_t *own_sq)
+                                     uint16_t *cand, uint16_t *legal, uint8_t *own_sq, Hook hook = Hook())
 {
     const int lane = XQ_LANE;
     const int from = move / 90, to = move % 90;
@@ -431,6 +437,7 @@ __device__ MoveResult wave_make_move(int8_t *bd, MState &s, int move, Hist &hist
     wave_sync();
     if (lane == 0) { bd[to] = (int8_t)moving; bd[from] = 0; }
     wave_sync();
+    hook(bd);
 
     if (moving == KING) s.rk = to; else if (moving == -KING) s.bk = to;           // :271-274
     if (captured == KING) s.rk = NO_KING; else if (captured == -KING) s.bk = NO_KING;   // :276-279

@@ -512,13 +512,20 @@ __global__ __launch_bounds__(64) void k_set_roots(Eng E, const int8_t *boards, c
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
 #error "dedupe_insert: cross-XCD visibility rests on gfx950's lowering of relaxed agent-scope atomics (write-through / L2 bypass) and on the gfx9 s_waitcnt encoding; validate before building for another target"
 #endif
-__device__ __forceinline__ void dedupe_insert(const Eng &E, int slot, uint32_t my_dword /* lane < 12: packed board dword */, int side)
+struct DedupeLook {            // what dedupe_prepare hands to dedupe_finish
+    unsigned pos;
+    unsigned long long ent;
+};
+
+// first half: publish the leaf's board and side (past the L2s), hash the position, take a first look at its table entry.
+// Nothing of this wave enters the table here: the caller may do other work (move generation) while the stores land.
+__device__ __forceinline__ DedupeLook dedupe_prepare(const Eng &E, int slot, uint32_t my_dword /* lane < 12: packed board dword */, int side)
 {
     const int lane = XQ_LANE;
     // This leaf's board and side must be visible to every other wave before the table can hand them the slot.  The L2s of
     // the 8 XCDs are not coherent with each other inside a kernel: an agent-scope release fence would write the whole L2
     // back (measured: k_search_round 87 -> 320 us); instead the few words other waves read are stored and loaded with
-    // agent-scope atomics (write-through / L2 bypass) and only their completion is waited for here.
+    // agent-scope atomics (write-through / L2 bypass) and only their completion is waited for (dedupe_finish).
     if (lane < 12) __hip_atomic_store(&E.leaf_board[(size_t)slot * 12 + lane], my_dword, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (lane == 0) __hip_atomic_store(&E.leaf_side[slot], (int8_t)side, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     uint64_t h = 0;
@@ -530,12 +537,21 @@ __device__ __forceinline__ void dedupe_insert(const Eng &E, int slot, uint32_t m
     }
     const uint32_t hlo = __builtin_amdgcn_readfirstlane((uint32_t)h), hhi = __builtin_amdgcn_readfirstlane((uint32_t)(h >> 32));
     h = mix64((((uint64_t)hhi << 32) | hlo) ^ (0x9E3779B97F4A7C15ull * (uint64_t)(side + 2)));
+    DedupeLook k;
+    k.pos = (unsigned)h & (unsigned)E.dd_mask;
+    // the first look at the table travels together with the stores above (the look is only a hint: the CAS decides)
+    k.ent = __hip_atomic_load(&E.dd_tab[k.pos], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return k;
+}
+
+// second half: once the stores of dedupe_prepare have landed, enter the table
+__device__ __forceinline__ void dedupe_finish(const Eng &E, int slot, uint32_t my_dword, int side, DedupeLook k)
+{
+    const int lane = XQ_LANE;
     const unsigned mask = (unsigned)E.dd_mask, tag = E.dd_tag;
-    unsigned pos = (unsigned)h & mask;
+    unsigned pos = k.pos;
+    unsigned long long ent = k.ent;
     const unsigned long long mine = ((unsigned long long)tag << 32) | (unsigned)slot;
-    // the first look at the table travels together with the stores above; nothing of this wave enters the table before
-    // both have come back (the look is only a hint: the CAS decides)
-    unsigned long long ent = __hip_atomic_load(&E.dd_tab[pos], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");             // (compiler ordering; a one-wave workgroup gets no wait from it)
     __builtin_amdgcn_s_waitcnt(0x0070);                                 // vmcnt(0) lgkmcnt(0): the stores have landed
     for (unsigned probes = 0; probes <= mask; probes++) {              // (the table holds >= 2 entries per slot: never full)
@@ -571,8 +587,14 @@ __device__ __forceinline__ void dedupe_insert(const Eng &E, int slot, uint32_t m
     if (lane == 0) E.leaf_pos[slot] = (int32_t)pos;
 }
 
+__device__ __forceinline__ void dedupe_insert(const Eng &E, int slot, uint32_t my_dword /* lane < 12: packed board dword */, int side)
+{
+    dedupe_finish(E, slot, my_dword, side, dedupe_prepare(E, slot, my_dword, side));
+}
+
 __device__ __forceinline__ void record_leaf(const Eng &E, int slot, WaveLds &L, const int8_t *bd, int side, int node,
-                            int depth, int mult, const uint16_t *moves, int n, void *planes, int fmt)
+                            int depth, int mult, const uint16_t *moves, int n, void *planes, int fmt,
+                            unsigned long long *st = nullptr)
 {
     const int lane = XQ_LANE;
     for (int j = lane; j < n; j += 64) E.leaf_moves[(size_t)slot * MAXM + j] = moves[j];
@@ -587,26 +609,40 @@ __device__ __forceinline__ void record_leaf(const Eng &E, int slot, WaveLds &L, 
         E.leaf_depth[slot] = (uint8_t)depth;
     }
     if (planes) write_planes(bd, side, planes, fmt, slot);
+    if (st && lane == 0) st[8] = __builtin_amdgcn_s_memtime();
     if (E.dedupe) dedupe_insert(E, slot, my_dword, side);     // (last: the planes' stores travel while it waits for the table)
+    if (st && lane == 0) st[9] = __builtin_amdgcn_s_memtime();
 }
+
+// Phase stamps (probes library only, xq_engine_set_search_stamps): lane 0 of every wave stores s_memtime at the phase
+// boundaries of a search round, 16 u64 per game: where a wave's ~50 k cycles go.
+#if XQ_TOWER_PROBES
+#define XQ_STAMP(i) do { if (STAMP && XQ_LANE == 0) stamps[(size_t)blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define XQ_STAMP(i) do { } while (0)
+#endif
 
 // OCC = minimum waves per SIMD requested from the register allocator.  The kernel is a chain of
 // dependent global loads (tree walk) with ~1.6 k VALU per wave, i.e. latency-bound: occupancy is
 // the lever (PMC: 62 % of wave cycles in s_waitcnt at 3 waves/SIMD).
-template <int OCC, bool VL>
-__global__ __launch_bounds__(64, OCC) void k_search_round(Eng E, int round, int batch_count, int eval_kind,
-                                                          const void *ev_a, const void *ev_v, void *planes, int fmt)
+// The round as rounds 1-4 ran it: every step loads what it needs when it needs it (~14 dependent memory round trips per
+// wave).  Since round 5 only the virtual-loss build (K pending leaves per game, opt-in extension) runs this body; the
+// reference's search - one pending leaf per game and round - runs search_round_one below.
+template <bool VL>
+__device__ void search_round_generic(const Eng &E, WaveLds &L, int round, int batch_count, int eval_kind,
+                                     const void *ev_a, const void *ev_v, void *planes, int fmt)
 {
-    // one wave = one game = one workgroup (packing 4 games into a 256-thread workgroup was
-    // measured 20-40 % slower at the same register budget: a workgroup retires only with its
-    // slowest game)
-    __shared__ WaveLds L;
+    constexpr bool STAMP = false;
+    unsigned long long *const stamps = nullptr;
     const int g = blockIdx.x, lane = XQ_LANE;
+    XQ_STAMP(0);
     const GameS gs = load_gs(E.gs + g);
     if (gs.done) return;
+    XQ_STAMP(1);
     const Tree T = tree_of(E, g);
     const int K = VL ? E.leaf_slots : 1;             // pending-leaf slots of this game: g * K + k
     int root = 0;
+    unsigned long long *const stp = nullptr;
 
     if (round == 0 && E.eval_carry && E.root_ready[g]) return;     // k_play_move already built this ply's expanded root
     if (round == 0) {
@@ -636,9 +672,11 @@ __global__ __launch_bounds__(64, OCC) void k_search_round(Eng E, int round, int 
         for (int k = 0; k < K; k++)
             consume_eval<VL>(E, g, g * K + k, L, T, root, eval_kind, ev_a, ev_v, gs.n_plies);
     }
+    XQ_STAMP(2);
 
     unpack_to_lds(E.board + (size_t)g * 12, L.root_bd);
     wave_sync();
+    XQ_STAMP(3);
 
     int sims_left = batch_count;
     int nslot = 0;                                   // VL: slots handed out in this round
@@ -652,6 +690,7 @@ __global__ __launch_bounds__(64, OCC) void k_search_round(Eng E, int round, int 
             depth++;
         }
         wave_sync();
+        XQ_STAMP(4);
         int flags = T.fl[node];
         if (VL && !(flags & F_TERM) && T.vl[node] != 0) {
             // this leaf is already waiting for the network in one of this round's slots: one more
@@ -668,7 +707,7 @@ __global__ __launch_bounds__(64, OCC) void k_search_round(Eng E, int round, int 
             if (node == root) {
                 // the root is never terminal (the driver checked legal moves, self_play.py:205-208)
                 record_leaf(E, g * K + nslot, L, L.root_bd, gs.side, root, 0, VL ? 1 : sims_left,
-                            E.root_moves + (size_t)g * MAXM, gs.n_root, planes, fmt);
+                            E.root_moves + (size_t)g * MAXM, gs.n_root, planes, fmt, stp);
                 if (!VL) return;
                 if (lane == 0) T.vl[root] += 1;
                 mem_fence_wave();
@@ -677,6 +716,7 @@ __global__ __launch_bounds__(64, OCC) void k_search_round(Eng E, int round, int 
                 continue;
             }
             // ---- replay the path on a copy of the root env (_copy_env, self_play.py:156-175)
+            if (STAMP && lane == 0 && (flags & 1) == 0) stp[5] = __builtin_amdgcn_s_memtime();      // (flags: depends on the load)
             for (int s = lane; s < 24; s += 64)
                 reinterpret_cast<uint32_t *>(L.bd)[s] = reinterpret_cast<const uint32_t *>(L.root_bd)[s];
             wave_sync();
@@ -700,17 +740,19 @@ __global__ __launch_bounds__(64, OCC) void k_search_round(Eng E, int round, int 
                 st.side = -st.side;
                 st.move_count += 1;
             }
+            XQ_STAMP(6);
             MoveResult mr;
             if (E.want_check)
                 mr = wave_make_move<false, true>(L.bd, st, L.path_move[depth - 1], hist, L.maps, L.cand, L.legal, L.own_sq);
             else
                 mr = wave_make_move<false, false>(L.bd, st, L.path_move[depth - 1], hist, L.maps, L.cand, L.legal, L.own_sq);
             flags |= mr.is_check ? F_CHECK : 0;
+            XQ_STAMP(7);
             const bool terminal = (mr.n_legal == 0) || (st.winner != WINNER_NONE);     // self_play.py:126
             if (!terminal) {
                 if (lane == 0) T.fl[node] = (uint8_t)flags;
                 record_leaf(E, g * K + nslot, L, L.bd, st.side, node, depth, VL ? 1 : sims_left, L.legal, mr.n_legal,
-                            planes, fmt);
+                            planes, fmt, stp);
                 if (!VL) return;
                 if (lane <= depth) { const int x = lane == 0 ? root : L.path_node[lane - 1]; T.vl[x] += 1; }
                 mem_fence_wave();
@@ -728,6 +770,356 @@ __global__ __launch_bounds__(64, OCC) void k_search_round(Eng E, int round, int 
         backup(T, root, L.path_node, depth, v, 1);                                     // self_play.py:135
         sims_left--;
     }
+}
+
+// self_play.py:40-59 on the root's children held in registers (lane j: children j and j + 64): the same float32 steps
+// in the same order as select_child, first maximum wins
+__device__ __forceinline__ int select_child_regs(int nc, uint32_t n_parent, uint32_t n0, uint32_t n1, double w0, double w1,
+                                                 float p0, float p1)
+{
+    const int lane = XQ_LANE;
+    const float sq = (float)sqrt((double)n_parent);
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const int c = lane + 64 * h;
+        if (c < nc) {
+            const uint32_t n = h ? n1 : n0;
+            const double w = h ? w1 : w0;
+            const float p = h ? p1 : p0;
+            float q = n ? (float)(w / (double)n) : 0.0f;
+            float t = 1.5f * p;
+            t = t * sq;
+            t = t / (float)(1u + n);
+            float sc = q + t;
+            if (sc > best) { best = sc; bi = c; }
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        float os = __shfl_xor(best, d, 64);
+        int oi = __shfl_xor(bi, d, 64);
+        if (os > best || (os == best && oi < bi)) { best = os; bi = oi; }
+    }
+    return uni(bi);
+}
+
+// value of child `c` (wave-uniform) out of a pair of per-lane registers (lane j: children j and j + 64)
+__device__ __forceinline__ int pick_child(int v0, int v1, int c)
+{
+    return (c < 64) ? __builtin_amdgcn_readlane(v0, c) : __builtin_amdgcn_readlane(v1, c - 64);
+}
+
+// One search round of one game (self_play.py:103-148), the reference's form: ONE pending leaf per game and round.
+// Round 5 restructure of the latency chain (tools/stamps_search.py: of a wave's ~41 k cycles, 11 k were consume_eval's
+// six dependent loads, 7.5 k the descent's three, 4 k the dedupe insert behind the leaf's stores):
+//   (A) everything addressed by the game alone - game record, pending-leaf header, its moves and path, its evaluator
+//       row, the arena fill, the root board, the root's node - is loaded in ONE round trip at the top;
+//   (B) the second round trip carries the policy columns of the pending moves, the W / N of the path's nodes for the
+//       backup AND the root's children (N, W, P, move, child block, flags) for this round's descent;
+//   (C) the third the logits.  The expansion and the backup then update memory as before and the same values in the
+//       registers, so the first level of the descent - with random-init priors almost always the only one - and the
+//       chosen child's move / flags need no memory at all.  Deeper levels walk memory as before (select_child).
+//   The leaf's packed board, its planes and the first look at the dedupe table leave right after the board is updated
+//   (wave_make_move's hook), so the table insert no longer waits a round trip behind ~3 KB of stores.
+template <bool STAMP>
+__device__ void search_round_one(const Eng &E, WaveLds &L, int round, int batch_count, int eval_kind,
+                                 const void *ev_a, const void *ev_v, void *planes, int fmt, unsigned long long *stamps)
+{
+    const int g = blockIdx.x, lane = XQ_LANE, slot = g;
+    XQ_STAMP(0);
+    const Tree T = tree_of(E, g);
+    unsigned long long *const stp = STAMP ? stamps + (size_t)g * 16 : nullptr;
+
+    // ---- (A)
+    const GameS gs = load_gs(E.gs + g);
+    const int ready = (round == 0 && E.eval_carry) ? E.root_ready[g] : 0;
+    const uint32_t bw = lane < 12 ? E.board[(size_t)g * 12 + lane] : 0u;
+    int root = 0;
+    int p_node = LEAF_NONE, p_n = 0, p_mult = 0, p_depth = 0, p_row = slot, p_first = 0, m0 = 0, m1 = 0, pth = 0;
+    if (round > 0) {
+        if (E.tree_reuse) root = E.root_node[g];
+        p_node = E.leaf_node[slot]; p_n = E.leaf_n[slot]; p_mult = E.leaf_mult[slot]; p_depth = E.leaf_depth[slot];
+        if (E.compact) p_row = E.leaf_row[slot];
+        p_first = (int)E.n_nodes[g];
+        m0 = E.leaf_moves[(size_t)slot * MAXM + lane];
+        m1 = E.leaf_moves[(size_t)slot * MAXM + 64 + lane];
+        pth = E.leaf_path[(size_t)slot * PATH_CAP + lane];
+    }
+    int r_nc = T.nc[root], r_first = T.first[root];
+    uint32_t r_N = T.N[root];
+    if (gs.done) return;
+    if (ready) return;                               // k_play_move already built this ply's expanded root
+    XQ_STAMP(1);
+    if (lane < 12) {                                 // root board -> LDS (unpack_to_lds from the register)
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const uint32_t code = (bw >> (4 * j)) & 15u;
+            L.root_bd[8 * lane + j] = (int8_t)(code <= 7 ? (int)code : 7 - (int)code);
+        }
+    }
+
+    if (round == 0) {
+        // tree reuse (opt-in): k_play_move left the played child as the root when it had been
+        // expanded; keep its subtree while a whole ply's expansions still fit the arena
+        if (E.tree_reuse) {
+            root = E.root_node[g];
+            if (root != 0 && (T.nc[root] == 0 || (int)E.n_nodes[g] + E.nrounds * MAXM > E.ncap)) root = 0;
+        }
+        if (root == 0) {
+            if (lane == 0) {                         // fresh tree every ply (self_play.py:98)
+                T.N[0] = 0; T.W[0] = 0.0; T.P[0] = 0.f; T.mv[0] = 0; T.first[0] = 0; T.nc[0] = 0; T.fl[0] = 0;
+                E.n_nodes[g] = 1; E.root_node[g] = 0;
+                E.leaf_node[slot] = LEAF_NONE;
+            }
+            r_nc = 0; r_first = 0; r_N = 0;
+        } else {
+            if (E.noise_eps > 0.0) {                 // the kept root gets this ply's noise on its stored priors
+                const int n = T.nc[root], first = T.first[root];
+                float q0 = lane < n ? T.P[first + lane] : 0.f, q1 = lane + 64 < n ? T.P[first + lane + 64] : 0.f;
+                root_noise(E, g, gs.n_plies, n, q0, q1);
+                if (lane < n) T.P[first + lane] = q0;
+                if (lane + 64 < n) T.P[first + lane + 64] = q1;
+            }
+            r_nc = T.nc[root]; r_first = T.first[root]; r_N = T.N[root];
+        }
+        mem_fence_wave();
+    }
+    r_nc = uni(r_nc); r_first = uni(r_first); r_N = (uint32_t)uni((int)r_N);
+    p_node = uni(p_node); p_n = uni(p_n); p_mult = uni(p_mult); p_depth = uni(p_depth); p_row = uni(p_row); p_first = uni(p_first);
+    const bool pending = p_node != LEAF_NONE;        // (round 0: never)
+
+    // ---- (B): the root's children as they stand before this round's expansion / backup
+    uint32_t cN0 = 0, cN1 = 0;
+    double cW0 = 0.0, cW1 = 0.0;
+    float cP0 = 0.f, cP1 = 0.f;
+    int cmv0 = 0, cmv1 = 0, cnc0 = 0, cnc1 = 0, cfl0 = 0, cfl1 = 0, cfc0 = 0, cfc1 = 0;
+    if (lane < r_nc) {
+        const int x = r_first + lane;
+        cN0 = T.N[x]; cW0 = T.W[x]; cP0 = T.P[x]; cmv0 = T.mv[x]; cnc0 = T.nc[x]; cfl0 = T.fl[x]; cfc0 = T.first[x];
+    }
+    if (lane + 64 < r_nc) {
+        const int x = r_first + lane + 64;
+        cN1 = T.N[x]; cW1 = T.W[x]; cP1 = T.P[x]; cmv1 = T.mv[x]; cnc1 = T.nc[x]; cfl1 = T.fl[x]; cfc1 = T.first[x];
+    }
+    if (pending) {
+        // ---- consume the evaluator's output for the pending leaf (self_play.py:61-68 + 146-148)
+        const int n = p_n, mult = p_mult, depth = p_depth;
+        const int prev = __shfl_up(pth, 1, 64);                              // lane l: node on level l of the path
+        const int bx = lane == 0 ? root : prev;
+        double bW = 0.0;
+        uint32_t bN = 0;
+        if (lane <= depth) { bW = T.W[bx]; bN = T.N[bx]; }
+        if (lane < depth) L.path_node[lane] = (uint16_t)pth;
+        double v;
+        float p0 = 0.f, p1 = 0.f;
+        if (eval_kind == XQ_EVAL_PRIORS) {
+            const float *pr = reinterpret_cast<const float *>(ev_a) + (size_t)slot * MAXM;
+            if (lane < n) p0 = pr[lane];
+            if (lane + 64 < n) p1 = pr[lane + 64];
+            v = reinterpret_cast<const double *>(ev_v)[slot];
+        } else {
+            // neural_network.py:148-169: gather the legal logits, float32 softmax over them
+            float x0 = -INFINITY, x1 = -INFINITY;
+            const int stride = E.col_map ? E.n_cols : XQ_POLICY_SIZE;
+            const int c0 = (E.col_map && lane < n) ? E.col_map[m0] : m0;
+            const int c1 = (E.col_map && lane + 64 < n) ? E.col_map[m1] : m1;
+            // ---- (C)
+            if (eval_kind == XQ_EVAL_LOGITS_F32) {
+                const float *lg = reinterpret_cast<const float *>(ev_a) + (size_t)p_row * stride;
+                if (lane < n) x0 = lg[c0];
+                if (lane + 64 < n) x1 = lg[c1];
+                v = (double)reinterpret_cast<const float *>(ev_v)[p_row];
+            } else {
+                const uint16_t *lg = reinterpret_cast<const uint16_t *>(ev_a) + (size_t)p_row * stride;
+                if (lane < n) x0 = bf16_to_f32(lg[c0]);
+                if (lane + 64 < n) x1 = bf16_to_f32(lg[c1]);
+                v = (double)bf16_to_f32(reinterpret_cast<const uint16_t *>(ev_v)[p_row]);
+            }
+            float mx = fmaxf(x0, x1);
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d, 64));
+            float e0 = lane < n ? expf(x0 - mx) : 0.f, e1 = lane + 64 < n ? expf(x1 - mx) : 0.f;
+            float sum = e0 + e1;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d, 64);
+            p0 = e0 / sum; p1 = e1 / sum;
+        }
+        if (E.noise_eps > 0.0 && p_node == root) root_noise(E, g, gs.n_plies, n, p0, p1);
+        const bool fits = p_first + n <= E.ncap;
+        if (fits) {
+            if (lane < n) {
+                const int x = p_first + lane;
+                T.N[x] = 0; T.W[x] = 0.0; T.P[x] = p0; T.mv[x] = (uint16_t)m0; T.first[x] = 0; T.nc[x] = 0; T.fl[x] = 0;
+            }
+            if (lane + 64 < n) {
+                const int x = p_first + lane + 64;
+                T.N[x] = 0; T.W[x] = 0.0; T.P[x] = p1; T.mv[x] = (uint16_t)m1; T.first[x] = 0; T.nc[x] = 0; T.fl[x] = 0;
+            }
+            if (lane == 0) { T.first[p_node] = (uint16_t)p_first; T.nc[p_node] = (uint8_t)n; E.n_nodes[g] = (uint32_t)(p_first + n); }
+        }
+        // self_play.py:70-80: `mult` sequential updates of value v at the leaf, signs alternating towards the root
+        const double sv = ((depth - lane) & 1) ? -v : v;
+        double w = bW;
+        for (int i = 0; i < mult; i++) w += sv;
+        if (lane <= depth) { T.W[bx] = w; T.N[bx] = bN + (uint32_t)mult; }
+        if (lane == 0) E.leaf_node[slot] = LEAF_NONE;
+        // ... and the same updates on the registers the descent reads
+        r_N += (uint32_t)mult;
+        if (depth == 0) {                                                    // the pending leaf was the root: its children are the new edges
+            if (fits) {
+                r_nc = n; r_first = p_first;
+                cN0 = cN1 = 0; cW0 = cW1 = 0.0; cP0 = p0; cP1 = p1; cmv0 = m0; cmv1 = m1;
+                cnc0 = cnc1 = cfl0 = cfl1 = cfc0 = cfc1 = 0;
+            }
+        } else {
+            const int ci = __builtin_amdgcn_readlane(pth, 0) - r_first;      // the root's child on the path
+            const double w1 = __shfl(w, 1, 64);                              // its updated W (lane 1 of the backup)
+            if (lane == (ci & 63)) {
+                if (ci < 64) { cW0 = w1; cN0 += (uint32_t)mult; } else { cW1 = w1; cN1 += (uint32_t)mult; }
+                if (depth == 1 && fits) {                                    // ... which is the leaf that was just expanded
+                    if (ci < 64) { cnc0 = n; cfc0 = p_first; } else { cnc1 = n; cfc1 = p_first; }
+                }
+            }
+        }
+        mem_fence_wave();
+    }
+    wave_sync();
+    XQ_STAMP(2);
+    XQ_STAMP(3);
+
+    int sims_left = batch_count;
+    bool from_regs = true;                           // the registers mirror memory until a terminal leaf's backup
+    while (sims_left > 0) {
+        // ---- select (self_play.py:117-119); the tree is frozen unless a terminal leaf updates it
+        int node = root, depth = 0, flags;
+        if (from_regs) {
+            int nc_node = r_nc;
+            flags = -1;
+            if (r_nc != 0) {
+                const int c = select_child_regs(r_nc, r_N, cN0, cN1, cW0, cW1, cP0, cP1);
+                node = r_first + c;
+                const int mv = pick_child(cmv0, cmv1, c);
+                nc_node = pick_child(cnc0, cnc1, c);
+                flags = pick_child(cfl0, cfl1, c);
+                if (lane == 0) { L.path_node[0] = (uint16_t)node; L.path_move[0] = (uint16_t)mv; }
+                depth = 1;
+            }
+            while (nc_node != 0 && depth < PATH_CAP) {
+                const int child = select_child<false>(T, node);
+                if (lane == 0) { L.path_node[depth] = (uint16_t)child; L.path_move[depth] = T.mv[child]; }
+                node = child;
+                depth++;
+                nc_node = T.nc[node];
+                flags = -1;
+            }
+            wave_sync();
+            XQ_STAMP(4);
+            if (flags < 0) flags = T.fl[node];
+            from_regs = false;
+        } else {
+            while (T.nc[node] != 0 && depth < PATH_CAP) {
+                const int child = select_child<false>(T, node);
+                if (lane == 0) { L.path_node[depth] = (uint16_t)child; L.path_move[depth] = T.mv[child]; }
+                node = child;
+                depth++;
+            }
+            wave_sync();
+            flags = T.fl[node];
+        }
+        if (!(flags & F_TERM)) {
+            if (node == root) {
+                // the root is never terminal (the driver checked legal moves, self_play.py:205-208)
+                record_leaf(E, slot, L, L.root_bd, gs.side, root, 0, sims_left, E.root_moves + (size_t)g * MAXM, gs.n_root,
+                            planes, fmt, stp);
+                return;
+            }
+            // ---- replay the path on a copy of the root env (_copy_env, self_play.py:156-175)
+            XQ_STAMP(5);
+            for (int s = lane; s < 24; s += 64)
+                reinterpret_cast<uint32_t *>(L.bd)[s] = reinterpret_cast<const uint32_t *>(L.root_bd)[s];
+            wave_sync();
+            MState st = to_mstate(gs);
+            st.cchk = 0; st.reason = R_NONE;
+            HistPath hist{ L.path_key, L.path_chk, 0, depth >= 6 };
+            for (int i = 0; i + 1 < depth; i++) {
+                // interior nodes were classified non-terminal when first reached; only the
+                // state that later plies read is replayed (board, caches, counters, history)
+                const int mv = L.path_move[i], from = mv / 90, to = mv % 90;
+                const int captured = L.bd[to], moving = L.bd[from];
+                wave_sync();
+                if (lane == 0) { L.bd[to] = (int8_t)moving; L.bd[from] = 0; }
+                wave_sync();
+                if (moving == KING) st.rk = to; else if (moving == -KING) st.bk = to;
+                if (captured == KING) st.rk = NO_KING; else if (captured == -KING) st.bk = NO_KING;
+                if (captured != 0) st.nocap = 0; else st.nocap += 1;
+                const uint64_t key = hist.keys_on ? position_key(L.bd, st.side == 1 ? 0 : 1) : 0ull;
+                const int chk = (T.fl[L.path_node[i]] & F_CHECK) ? 1 : 0;
+                hist.push(key, chk);
+                st.side = -st.side;
+                st.move_count += 1;
+            }
+            XQ_STAMP(6);
+            // the leaf's position is known the moment its last move is on the board: its packed board (for the dedupe:
+            // past the L2s), its planes and the first look at its table entry leave before the move generation
+            const int leaf_side = -st.side;
+            uint32_t my_dword = 0;
+            DedupeLook look{ 0u, 0ull };
+            auto early = [&](const int8_t *bd) {
+                my_dword = lane < 12 ? pack_dword(bd, lane) : 0u;
+                if (E.dedupe) look = dedupe_prepare(E, slot, my_dword, leaf_side);
+                else {
+                    if (lane < 12) E.leaf_board[(size_t)slot * 12 + lane] = my_dword;
+                    if (lane == 0) E.leaf_side[slot] = (int8_t)leaf_side;
+                }
+                if (planes) write_planes(bd, leaf_side, planes, fmt, slot);
+            };
+            MoveResult mr;
+            if (E.want_check)
+                mr = wave_make_move<false, true>(L.bd, st, L.path_move[depth - 1], hist, L.maps, L.cand, L.legal, L.own_sq, early);
+            else
+                mr = wave_make_move<false, false>(L.bd, st, L.path_move[depth - 1], hist, L.maps, L.cand, L.legal, L.own_sq, early);
+            flags |= mr.is_check ? F_CHECK : 0;
+            XQ_STAMP(7);
+            const bool terminal = (mr.n_legal == 0) || (st.winner != WINNER_NONE);     // self_play.py:126
+            if (!terminal) {
+                if (lane == 0) {
+                    T.fl[node] = (uint8_t)flags;
+                    E.leaf_node[slot] = (uint16_t)node; E.leaf_mult[slot] = (uint8_t)sims_left; E.leaf_n[slot] = (uint8_t)mr.n_legal;
+                    E.leaf_depth[slot] = (uint8_t)depth;
+                }
+                for (int j = lane; j < mr.n_legal; j += 64) E.leaf_moves[(size_t)slot * MAXM + j] = L.legal[j];
+                if (lane < depth) E.leaf_path[(size_t)slot * PATH_CAP + lane] = L.path_node[lane];
+                if (STAMP && lane == 0) stp[8] = __builtin_amdgcn_s_memtime();
+                if (E.dedupe) dedupe_finish(E, slot, my_dword, leaf_side, look);
+                if (STAMP && lane == 0) stp[9] = __builtin_amdgcn_s_memtime();
+                return;
+            }
+            // self_play.py:128-133, value from the side to move at the leaf
+            flags |= F_TERM;
+            if (st.winner == st.side) flags |= F_VAL_POS;
+            else if (st.winner == -st.side) flags |= F_VAL_NEG;
+            if (lane == 0) T.fl[node] = (uint8_t)flags;
+        }
+        const double v = (flags & F_VAL_POS) ? 1.0 : ((flags & F_VAL_NEG) ? -1.0 : 0.0);
+        backup(T, root, L.path_node, depth, v, 1);                                     // self_play.py:135
+        sims_left--;
+    }
+}
+
+// OCC = minimum waves per SIMD requested from the register allocator.
+template <int OCC, bool VL, bool STAMP = false>
+__global__ __launch_bounds__(64, OCC) void k_search_round(Eng E, int round, int batch_count, int eval_kind,
+                                                          const void *ev_a, const void *ev_v, void *planes, int fmt,
+                                                          unsigned long long *stamps = nullptr)
+{
+    // one wave = one game = one workgroup (packing 4 games into a 256-thread workgroup was
+    // measured 20-40 % slower at the same register budget: a workgroup retires only with its
+    // slowest game)
+    __shared__ WaveLds L;
+    if constexpr (VL) search_round_generic<true>(E, L, round, batch_count, eval_kind, ev_a, ev_v, planes, fmt);
+    else search_round_one<STAMP>(E, L, round, batch_count, eval_kind, ev_a, ev_v, planes, fmt, stamps);
 }
 
 __constant__ uint32_t c_crc_table[256];
@@ -1833,6 +2225,19 @@ static int g_search_occ = 4;      // 128 VGPRs, 4 waves/SIMD: fastest of {3, 4, 
                                   // 56 B/lane of scratch that also adds 46 MB of HBM writes per launch)
 // diagnostic (include/xq_debug.h): register budget variant of k_search_round
 extern "C" void xq_engine_set_search_occupancy(int waves_per_simd) { g_search_occ = waves_per_simd; }
+// diagnostic (include/xq_debug.h): device buffer of 16 u64 per game for k_search_round's phase stamps (probes library
+// only; NULL = off).  Every launch overwrites it: read it after the round of interest.
+static void *g_search_stamps = nullptr;
+extern "C" int xq_engine_set_search_stamps(void *dev_u64x16_per_game)
+{
+#if XQ_TOWER_PROBES
+    g_search_stamps = dev_u64x16_per_game;
+    return 0;
+#else
+    (void)dev_u64x16_per_game;
+    return XQ_E_INVALID;
+#endif
+}
 
 extern "C" int xq_engine_search_round(xq_engine *e, int round, int eval_kind, const void *ev_a, const void *ev_v,
                                       void *planes)
@@ -1863,8 +2268,13 @@ extern "C" int xq_engine_search_round(xq_engine *e, int round, int eval_kind, co
         e->E.dd_tag = e->dd_tag;
     }
 #define XQ_LAUNCH_SEARCH(OCC, VLB) hipLaunchKernelGGL((k_search_round<OCC, VLB>), dim3(e->E.G), dim3(64), 0, e->stream, e->E, \
-                                                    round, batch, eval_kind, ev_a, ev_v, planes, fmt)
+                                                    round, batch, eval_kind, ev_a, ev_v, planes, fmt, (unsigned long long *)nullptr)
     if (e->E.vloss) XQ_LAUNCH_SEARCH(4, true);
+#if XQ_TOWER_PROBES
+    else if (g_search_stamps)
+        hipLaunchKernelGGL((k_search_round<4, false, true>), dim3(e->E.G), dim3(64), 0, e->stream, e->E, round, batch, eval_kind,
+                           ev_a, ev_v, planes, fmt, (unsigned long long *)g_search_stamps);
+#endif
     else switch (g_search_occ) {
 #if XQ_TOWER_PROBES                 // the other register budgets spill 27-58 VGPRs: comparison builds, probes library only
     case 3: XQ_LAUNCH_SEARCH(3, false); break;

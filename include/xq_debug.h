@@ -73,6 +73,12 @@ int  xq_policy_fc_debug_stamps(int nodma, void *hip_stream, const void *act_dev,
  * 8; any other value means 4.  Same results. */
 void xq_engine_set_search_occupancy(int waves_per_simd);
 
+/* Phase stamps of k_search_round (probes library only; XQ_E_INVALID otherwise): a device buffer of 16 uint64 per game
+ * that lane 0 of every game's wave fills with s_memtime at the phase boundaries of the round (0 start, 1 game record
+ * loaded, 2 evaluator output consumed, 3 root board unpacked, 4 descent done, 5 leaf flags loaded, 6 path replayed,
+ * 7 make_move done, 8 leaf record + planes stored, 9 dedupe insert done).  NULL switches them off.  Process-wide. */
+int  xq_engine_set_search_stamps(void *dev_u64x16_per_game);
+
 #ifdef __cplusplus
 }
 #endif
