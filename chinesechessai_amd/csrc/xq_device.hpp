@@ -425,11 +425,13 @@ struct MoveResult {
 //
 // `hook(bd)` runs once, wave-convergent, as soon as the board holds the new position - before the check test and the
 // move generation: the search kernel uses it to send the leaf's board, planes and table look on their way early.
+// `check_now` (wave-uniform, with WANT_CHECK): compute :317's is_checking; the search skips it while no path can
+// hold the 12 plies the perpetual-check rule reads (one instantiation instead of two: half the kernel's code).
 struct NoHook { __device__ void operator()(const int8_t *) const {} };
 
 template <bool WANT_REWARD, bool WANT_CHECK, class Hist, class Hook = NoHook>
 __device__ MoveResult wave_make_move(int8_t *bd, MState &s, int move, Hist &hist, AttackMaps &M,
-                                     uint16_t *cand, uint16_t *legal, uint8_t *own_sq, Hook hook = Hook())
+                                     uint16_t *cand, uint16_t *legal, uint8_t *own_sq, Hook hook = Hook(), bool check_now = true)
 {
     const int lane = XQ_LANE;
     const int from = move / 90, to = move % 90;
@@ -439,9 +441,11 @@ __device__ MoveResult wave_make_move(int8_t *bd, MState &s, int move, Hist &hist
     wave_sync();
     hook(bd);
 
-    if (moving == KING) s.rk = to; else if (moving == -KING) s.bk = to;           // :271-274
-    if (captured == KING) s.rk = NO_KING; else if (captured == -KING) s.bk = NO_KING;   // :276-279
-    if (captured != 0) s.nocap = 0; else s.nocap += 1;                             // :282-285
+    // (value selects, not conditional stores: `if (a) s.rk = x; else if (b) s.bk = x;` becomes a store through a selected
+    // pointer, which keeps the whole MState in scratch memory - a memory round trip per access)
+    s.rk = (captured == KING) ? NO_KING : ((moving == KING) ? to : s.rk);          // :271-279
+    s.bk = (captured == -KING) ? NO_KING : ((moving == -KING) ? to : s.bk);
+    s.nocap = (captured != 0) ? 0 : s.nocap + 1;                                   // :282-285
 
     MoveResult res;
     res.reward = 0; res.done = 0; res.n_legal = 0;
@@ -461,7 +465,7 @@ __device__ MoveResult wave_make_move(int8_t *bd, MState &s, int move, Hist &hist
     // next side's suicide filter (:431-464) and that side's in-check test (:625,641) - one set of maps
     const uint32_t kab_rows = build_attack_maps(M, v, s.side);
     int is_checking = 0;
-    if (WANT_CHECK) is_checking = uni(in_check(M, kab_rows, s.side == 1 ? s.bk : s.rk, s.side) ? 1 : 0);   // :317
+    if (WANT_CHECK && check_now) is_checking = uni(in_check(M, kab_rows, s.side == 1 ? s.bk : s.rk, s.side) ? 1 : 0);   // :317
     res.is_check = is_checking;
     if (!res.done && is_checking) {                                                // :318-327
         if (WANT_REWARD) {

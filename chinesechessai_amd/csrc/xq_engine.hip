@@ -56,25 +56,48 @@ enum : int { F_TERM = 2, F_VAL_NEG = 4, F_VAL_POS = 8, F_CHECK = 16 };
 enum : int { PATH_CAP = 72, LEAF_NONE = 0xFFFF };
 
 struct Eng {
-    int G, ncap, sims, leaf_batch, nrounds, max_moves, opponent_mode, want_check;
-    double temperature;
-    uint32_t *board;          // [G][12]
+    // (the kernel argument is ~0.5 KB, more than a wave's scalar registers: the fields are ordered by the phase of
+    // k_search_round that reads them, so that each phase's pointers arrive in one or two wide scalar loads)
+    // ---- phase A of a search round: everything addressed by the game alone
     GameS    *gs;             // [G]
+    uint32_t *board;          // [G][12]
+    uint16_t *leaf_node; uint8_t *leaf_n; uint8_t *leaf_mult; uint8_t *leaf_depth;      // pending leaf per slot
+    uint16_t *leaf_moves;     // [slots][128]
+    uint16_t *leaf_path;      // [slots][PATH_CAP]
+    uint32_t *n_nodes;        // [G]
+    // evaluator row compaction (xq_engine_set_row_compaction): only slots with a pending leaf become network rows.
+    // k_assign_rows numbers them in slot order after every search round: leaf_row[slot] = row or -1,
+    // row_src[row] = slot (where the search kernel wrote the planes), row_count[0] = rows of this round
+    int32_t *leaf_row, *row_src, *row_count, *row_hist;
+    // tree root per game: always node 0 (fresh tree every ply, self_play.py:98) unless the opt-in
+    // tree reuse keeps the played child's subtree (extension, SURVEY.md §8f rank 4)
+    uint16_t *root_node;
+    // opt-in: carry the played child's network evaluation over as the next root's (xq_engine_set_root_eval_carry)
+    uint8_t *root_ready; int32_t *roots_not_ready;
+    int G, ncap, compact, tree_reuse, eval_carry, dedupe, dd_mask;
+    unsigned dd_tag;          // tag of the round being launched (set by the host before every k_search_round)
+    // ---- phase B: node arena, [G][ncap] each; the compact policy layout
+    uint32_t *nN; double *nW; float *nP; uint16_t *nMove; uint16_t *nFirst; uint8_t *nNc; uint8_t *nFlags;
+    // optional compact policy layout: logits rows hold only n_cols columns, col_map[move] = column
+    const int16_t *col_map; int n_cols;
+    int sims, leaf_batch, nrounds, max_moves, opponent_mode, want_check;
+    // ---- the rest of a round: leaf record, dedupe table
+    uint32_t *leaf_board;     // [slots][12]
+    int8_t   *leaf_side;      // [slots]
+    uint16_t *root_moves;     // [G][128]
+    // leaf dedupe (xq_engine_set_leaf_dedupe, needs compaction): slots whose pending leaves are the same position
+    // (board + side to move) share one network row.  dd_tab = open-addressing table of (round tag << 32 | lowest
+    // slot of the position), dd_mask + 1 entries; leaf_pos[slot] = the entry dedupe_insert found for the slot
+    unsigned long long *dd_tab;
+    int32_t *leaf_pos;
+    uint8_t *leaf_dup;        // [slots] 1 = a lower slot holds the same position (cleared by k_assign_rows after reading)
+    float    *priors;         // [slots][128]
+    double   *values;         // [slots]
+    // ---- per ply
+    double temperature;
     uint64_t *pos_hist;       // [G][PATH_CAP]
     uint8_t  *chk_hist;       // [G][PATH_CAP]
-    uint16_t *root_moves;     // [G][128]
     double   *uniforms;       // [G][70]
-    // node arena, [G][ncap] each
-    uint32_t *nN; double *nW; float *nP; uint16_t *nMove; uint16_t *nFirst; uint8_t *nNc; uint8_t *nFlags;
-    uint32_t *n_nodes;        // [G]
-    // pending leaf per game
-    uint16_t *leaf_node; uint8_t *leaf_mult; uint8_t *leaf_n; uint8_t *leaf_depth;
-    uint16_t *leaf_moves;     // [G][128]
-    uint16_t *leaf_path;      // [G][PATH_CAP]
-    uint32_t *leaf_board;     // [G][12]
-    int8_t   *leaf_side;      // [G]
-    float    *priors;         // [G][128]
-    double   *values;         // [G]
     // samples, [G][70]
     uint32_t *s_board; int8_t *s_player; uint8_t *s_n; uint16_t *s_moves; uint16_t *s_counts; double *s_z;
     double   *step_reward; uint16_t *t_move;
@@ -83,31 +106,11 @@ struct Eng {
     // noise_eps == 0 keeps the reference behaviour
     double noise_alpha, noise_eps;
     uint64_t noise_seed;
-    // optional compact policy layout: logits rows hold only n_cols columns, col_map[move] = column
-    const int16_t *col_map; int n_cols;
-    // tree root per game: always node 0 (fresh tree every ply, self_play.py:98) unless the opt-in
-    // tree reuse keeps the played child's subtree (extension, SURVEY.md §8f rank 4)
-    uint16_t *root_node; int tree_reuse;
-    // opt-in: carry the played child's network evaluation over as the next root's (xq_engine_set_root_eval_carry)
-    int eval_carry; uint8_t *root_ready; int32_t *roots_not_ready;
     // virtual loss (opt-in extension): K = leaf_slots pending leaves per game and round instead of one
     // (every leaf_* / priors / values array and the evaluator's rows are indexed by slot = g * K + k);
     // nVl counts the pending visits through a node and is folded into PUCT as N + vl, W - vl
     int vloss, leaf_slots;
     uint8_t *nVl;
-    // evaluator row compaction (xq_engine_set_row_compaction): only slots with a pending leaf become network rows.
-    // k_assign_rows numbers them in slot order after every search round: leaf_row[slot] = row or -1,
-    // row_src[row] = slot (where the search kernel wrote the planes), row_count[0] = rows of this round
-    int compact;
-    int32_t *leaf_row, *row_src, *row_count, *row_hist;
-    // leaf dedupe (xq_engine_set_leaf_dedupe, needs compaction): slots whose pending leaves are the same position
-    // (board + side to move) share one network row.  dd_tab = open-addressing table of (round tag << 32 | lowest
-    // slot of the position), dd_mask + 1 entries; leaf_pos[slot] = the entry dedupe_insert found for the slot
-    int dedupe, dd_mask;
-    unsigned dd_tag;          // tag of the round being launched (set by the host before every k_search_round)
-    unsigned long long *dd_tab;
-    int32_t *leaf_pos;
-    uint8_t *leaf_dup;        // [slots] 1 = a lower slot holds the same position (cleared by k_assign_rows after reading)
 };
 
 struct __align__(16) WaveLds {
@@ -234,14 +237,15 @@ __device__ void write_planes(const int8_t *bd, int side, void *planes, int fmt, 
         }
     } else if (fmt == XQ_PLANES_NHWC16_BF16) {
         uint4 *o = reinterpret_cast<uint4 *>(planes) + (size_t)g * 180;     // 90 squares x 32 B
+        const uint32_t w7 = side == 1 ? 0x3F80u : 0u;                       // channel 14 (15 is padding)
         for (int s = lane; s < 90; s += 64) {
-            int p = bd[s];
-            int ch = p > 0 ? p - 1 : (p < 0 ? 6 - p : -1);
-            uint32_t w[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
-            if (ch >= 0) w[ch >> 1] = 0x3F80u << ((ch & 1) * 16);
-            if (side == 1) w[7] |= 0x3F80u;                                 // channel 14
-            o[2 * s] = make_uint4(w[0], w[1], w[2], w[3]);
-            o[2 * s + 1] = make_uint4(w[4], w[5], w[6], w[7]);
+            const int p = bd[s];
+            const int ch = p > 0 ? p - 1 : (p < 0 ? 6 - p : -2);            // 0..13, none: -2 (word -1)
+            const uint32_t val = 0x3F80u << ((ch & 1) * 16);
+            const int wi = ch >> 1;
+            // (selects, not an indexed local array: that would live in scratch memory - a round trip per store)
+            o[2 * s] = make_uint4(wi == 0 ? val : 0u, wi == 1 ? val : 0u, wi == 2 ? val : 0u, wi == 3 ? val : 0u);
+            o[2 * s + 1] = make_uint4(wi == 4 ? val : 0u, wi == 5 ? val : 0u, wi == 6 ? val : 0u, w7);
         }
     }
 }
@@ -731,9 +735,9 @@ __device__ void search_round_generic(const Eng &E, WaveLds &L, int round, int ba
                 wave_sync();
                 if (lane == 0) { L.bd[to] = (int8_t)moving; L.bd[from] = 0; }
                 wave_sync();
-                if (moving == KING) st.rk = to; else if (moving == -KING) st.bk = to;
-                if (captured == KING) st.rk = NO_KING; else if (captured == -KING) st.bk = NO_KING;
-                if (captured != 0) st.nocap = 0; else st.nocap += 1;
+                st.rk = (captured == KING) ? NO_KING : ((moving == KING) ? to : st.rk);
+                st.bk = (captured == -KING) ? NO_KING : ((moving == -KING) ? to : st.bk);
+                st.nocap = (captured != 0) ? 0 : st.nocap + 1;
                 const uint64_t key = hist.keys_on ? position_key(L.bd, st.side == 1 ? 0 : 1) : 0ull;
                 const int chk = (T.fl[L.path_node[i]] & F_CHECK) ? 1 : 0;
                 hist.push(key, chk);
@@ -832,23 +836,30 @@ __device__ void search_round_one(const Eng &E, WaveLds &L, int round, int batch_
     const Tree T = tree_of(E, g);
     unsigned long long *const stp = STAMP ? stamps + (size_t)g * 16 : nullptr;
 
-    // ---- (A)
-    const GameS gs = load_gs(E.gs + g);
-    const int ready = (round == 0 && E.eval_carry) ? E.root_ready[g] : 0;
+    // ---- (A): straight-line, no branch between the loads (a load under an `if` is issued when the branch is taken,
+    // i.e. one round trip later); what a round does not need is loaded from a valid address and ignored
+    union { uint4 u; GameS g; } gx;
+    gx.u = *reinterpret_cast<const uint4 *>(E.gs + g);
     const uint32_t bw = lane < 12 ? E.board[(size_t)g * 12 + lane] : 0u;
-    int root = 0;
-    int p_node = LEAF_NONE, p_n = 0, p_mult = 0, p_depth = 0, p_row = slot, p_first = 0, m0 = 0, m1 = 0, pth = 0;
-    if (round > 0) {
-        if (E.tree_reuse) root = E.root_node[g];
-        p_node = E.leaf_node[slot]; p_n = E.leaf_n[slot]; p_mult = E.leaf_mult[slot]; p_depth = E.leaf_depth[slot];
-        if (E.compact) p_row = E.leaf_row[slot];
-        p_first = (int)E.n_nodes[g];
-        m0 = E.leaf_moves[(size_t)slot * MAXM + lane];
-        m1 = E.leaf_moves[(size_t)slot * MAXM + 64 + lane];
-        pth = E.leaf_path[(size_t)slot * PATH_CAP + lane];
-    }
+    const uint8_t *ready_p = E.eval_carry ? E.root_ready + g : reinterpret_cast<const uint8_t *>(E.leaf_n + slot);
+    const int32_t *row_p = E.compact ? E.leaf_row + slot : reinterpret_cast<const int32_t *>(E.n_nodes + g);
+    const int ready_v = *ready_p;
+    const int row_v = *row_p;
+    const int root_v = E.root_node[g];
+    int p_node = E.leaf_node[slot], p_n = E.leaf_n[slot], p_mult = E.leaf_mult[slot], p_depth = E.leaf_depth[slot];
+    int p_first = (int)E.n_nodes[g];
+    const int m0 = E.leaf_moves[(size_t)slot * MAXM + lane], m1 = E.leaf_moves[(size_t)slot * MAXM + 64 + lane];
+    const int pth = E.leaf_path[(size_t)slot * PATH_CAP + lane];
+    int root = (round > 0 && E.tree_reuse) ? root_v : 0;
     int r_nc = T.nc[root], r_first = T.first[root];
     uint32_t r_N = T.N[root];
+    // (whole dwords of the game record: field-wise narrow loads would each be a request of their own)
+    gx.u.x = (uint32_t)uni((int)gx.u.x); gx.u.y = (uint32_t)uni((int)gx.u.y);
+    gx.u.z = (uint32_t)uni((int)gx.u.z); gx.u.w = (uint32_t)uni((int)gx.u.w);
+    const GameS gs = gx.g;
+    const int ready = (round == 0 && E.eval_carry) ? ready_v : 0;
+    int p_row = E.compact ? row_v : slot;
+    if (round == 0) p_node = LEAF_NONE;
     if (gs.done) return;
     if (ready) return;                               // k_play_move already built this ply's expanded root
     XQ_STAMP(1);
@@ -891,17 +902,19 @@ __device__ void search_round_one(const Eng &E, WaveLds &L, int round, int batch_
     const bool pending = p_node != LEAF_NONE;        // (round 0: never)
 
     // ---- (B): the root's children as they stand before this round's expansion / backup
-    uint32_t cN0 = 0, cN1 = 0;
+    // (cM = move | n_child << 16 | flags << 24 of the child: what the descent needs of the child it picks)
+    uint32_t cN0 = 0, cN1 = 0, cM0 = 0, cM1 = 0;
     double cW0 = 0.0, cW1 = 0.0;
     float cP0 = 0.f, cP1 = 0.f;
-    int cmv0 = 0, cmv1 = 0, cnc0 = 0, cnc1 = 0, cfl0 = 0, cfl1 = 0, cfc0 = 0, cfc1 = 0;
     if (lane < r_nc) {
         const int x = r_first + lane;
-        cN0 = T.N[x]; cW0 = T.W[x]; cP0 = T.P[x]; cmv0 = T.mv[x]; cnc0 = T.nc[x]; cfl0 = T.fl[x]; cfc0 = T.first[x];
+        cN0 = T.N[x]; cW0 = T.W[x]; cP0 = T.P[x];
+        cM0 = (uint32_t)T.mv[x] | ((uint32_t)T.nc[x] << 16) | ((uint32_t)T.fl[x] << 24);
     }
     if (lane + 64 < r_nc) {
         const int x = r_first + lane + 64;
-        cN1 = T.N[x]; cW1 = T.W[x]; cP1 = T.P[x]; cmv1 = T.mv[x]; cnc1 = T.nc[x]; cfl1 = T.fl[x]; cfc1 = T.first[x];
+        cN1 = T.N[x]; cW1 = T.W[x]; cP1 = T.P[x];
+        cM1 = (uint32_t)T.mv[x] | ((uint32_t)T.nc[x] << 16) | ((uint32_t)T.fl[x] << 24);
     }
     if (pending) {
         // ---- consume the evaluator's output for the pending leaf (self_play.py:61-68 + 146-148)
@@ -970,8 +983,7 @@ __device__ void search_round_one(const Eng &E, WaveLds &L, int round, int batch_
         if (depth == 0) {                                                    // the pending leaf was the root: its children are the new edges
             if (fits) {
                 r_nc = n; r_first = p_first;
-                cN0 = cN1 = 0; cW0 = cW1 = 0.0; cP0 = p0; cP1 = p1; cmv0 = m0; cmv1 = m1;
-                cnc0 = cnc1 = cfl0 = cfl1 = cfc0 = cfc1 = 0;
+                cN0 = cN1 = 0; cW0 = cW1 = 0.0; cP0 = p0; cP1 = p1; cM0 = (uint32_t)m0; cM1 = (uint32_t)m1;
             }
         } else {
             const int ci = __builtin_amdgcn_readlane(pth, 0) - r_first;      // the root's child on the path
@@ -979,7 +991,7 @@ __device__ void search_round_one(const Eng &E, WaveLds &L, int round, int batch_
             if (lane == (ci & 63)) {
                 if (ci < 64) { cW0 = w1; cN0 += (uint32_t)mult; } else { cW1 = w1; cN1 += (uint32_t)mult; }
                 if (depth == 1 && fits) {                                    // ... which is the leaf that was just expanded
-                    if (ci < 64) { cnc0 = n; cfc0 = p_first; } else { cnc1 = n; cfc1 = p_first; }
+                    if (ci < 64) cM0 = (cM0 & 0xff00ffffu) | ((uint32_t)n << 16); else cM1 = (cM1 & 0xff00ffffu) | ((uint32_t)n << 16);
                 }
             }
         }
@@ -989,35 +1001,41 @@ __device__ void search_round_one(const Eng &E, WaveLds &L, int round, int batch_
     XQ_STAMP(2);
     XQ_STAMP(3);
 
+    // ---- select (self_play.py:117-119), first simulation of the round: level 0 from the registers (done in front of
+    // the loop, so that the children's registers are dead before the move generation needs its own)
+    int node0 = root, depth0 = 0, flags0 = -1;
+    {
+        int nc_node = r_nc;
+        if (r_nc != 0) {
+            const int c = select_child_regs(r_nc, r_N, cN0, cN1, cW0, cW1, cP0, cP1);
+            node0 = r_first + c;
+            const uint32_t meta = (uint32_t)pick_child((int)cM0, (int)cM1, c);
+            nc_node = (int)((meta >> 16) & 0xffu);
+            flags0 = (int)(meta >> 24);
+            if (lane == 0) { L.path_node[0] = (uint16_t)node0; L.path_move[0] = (uint16_t)(meta & 0xffffu); }
+            depth0 = 1;
+        }
+        while (nc_node != 0 && depth0 < PATH_CAP) {
+            const int child = select_child<false>(T, node0);
+            if (lane == 0) { L.path_node[depth0] = (uint16_t)child; L.path_move[depth0] = T.mv[child]; }
+            node0 = child;
+            depth0++;
+            nc_node = T.nc[node0];
+            flags0 = -1;
+        }
+        wave_sync();
+        XQ_STAMP(4);
+        if (flags0 < 0) flags0 = T.fl[node0];
+    }
+
     int sims_left = batch_count;
-    bool from_regs = true;                           // the registers mirror memory until a terminal leaf's backup
+    bool first = true;
     while (sims_left > 0) {
-        // ---- select (self_play.py:117-119); the tree is frozen unless a terminal leaf updates it
+        // the tree is frozen unless a terminal leaf updates it: later simulations of the round walk memory
         int node = root, depth = 0, flags;
-        if (from_regs) {
-            int nc_node = r_nc;
-            flags = -1;
-            if (r_nc != 0) {
-                const int c = select_child_regs(r_nc, r_N, cN0, cN1, cW0, cW1, cP0, cP1);
-                node = r_first + c;
-                const int mv = pick_child(cmv0, cmv1, c);
-                nc_node = pick_child(cnc0, cnc1, c);
-                flags = pick_child(cfl0, cfl1, c);
-                if (lane == 0) { L.path_node[0] = (uint16_t)node; L.path_move[0] = (uint16_t)mv; }
-                depth = 1;
-            }
-            while (nc_node != 0 && depth < PATH_CAP) {
-                const int child = select_child<false>(T, node);
-                if (lane == 0) { L.path_node[depth] = (uint16_t)child; L.path_move[depth] = T.mv[child]; }
-                node = child;
-                depth++;
-                nc_node = T.nc[node];
-                flags = -1;
-            }
-            wave_sync();
-            XQ_STAMP(4);
-            if (flags < 0) flags = T.fl[node];
-            from_regs = false;
+        if (first) {
+            node = node0; depth = depth0; flags = flags0;
+            first = false;
         } else {
             while (T.nc[node] != 0 && depth < PATH_CAP) {
                 const int child = select_child<false>(T, node);
@@ -1051,9 +1069,9 @@ __device__ void search_round_one(const Eng &E, WaveLds &L, int round, int batch_
                 wave_sync();
                 if (lane == 0) { L.bd[to] = (int8_t)moving; L.bd[from] = 0; }
                 wave_sync();
-                if (moving == KING) st.rk = to; else if (moving == -KING) st.bk = to;
-                if (captured == KING) st.rk = NO_KING; else if (captured == -KING) st.bk = NO_KING;
-                if (captured != 0) st.nocap = 0; else st.nocap += 1;
+                st.rk = (captured == KING) ? NO_KING : ((moving == KING) ? to : st.rk);
+                st.bk = (captured == -KING) ? NO_KING : ((moving == -KING) ? to : st.bk);
+                st.nocap = (captured != 0) ? 0 : st.nocap + 1;
                 const uint64_t key = hist.keys_on ? position_key(L.bd, st.side == 1 ? 0 : 1) : 0ull;
                 const int chk = (T.fl[L.path_node[i]] & F_CHECK) ? 1 : 0;
                 hist.push(key, chk);
@@ -1075,11 +1093,8 @@ __device__ void search_round_one(const Eng &E, WaveLds &L, int round, int batch_
                 }
                 if (planes) write_planes(bd, leaf_side, planes, fmt, slot);
             };
-            MoveResult mr;
-            if (E.want_check)
-                mr = wave_make_move<false, true>(L.bd, st, L.path_move[depth - 1], hist, L.maps, L.cand, L.legal, L.own_sq, early);
-            else
-                mr = wave_make_move<false, false>(L.bd, st, L.path_move[depth - 1], hist, L.maps, L.cand, L.legal, L.own_sq, early);
+            const MoveResult mr = wave_make_move<false, true>(L.bd, st, L.path_move[depth - 1], hist, L.maps, L.cand, L.legal, L.own_sq,
+                                                              early, E.want_check != 0);
             flags |= mr.is_check ? F_CHECK : 0;
             XQ_STAMP(7);
             const bool terminal = (mr.n_legal == 0) || (st.winner != WINNER_NONE);     // self_play.py:126
@@ -1092,7 +1107,8 @@ __device__ void search_round_one(const Eng &E, WaveLds &L, int round, int batch_
                 for (int j = lane; j < mr.n_legal; j += 64) E.leaf_moves[(size_t)slot * MAXM + j] = L.legal[j];
                 if (lane < depth) E.leaf_path[(size_t)slot * PATH_CAP + lane] = L.path_node[lane];
                 if (STAMP && lane == 0) stp[8] = __builtin_amdgcn_s_memtime();
-                if (E.dedupe) dedupe_finish(E, slot, my_dword, leaf_side, look);
+                // (the packed board again from LDS: cheaper than a register held across the move generation)
+                if (E.dedupe) dedupe_finish(E, slot, lane < 12 ? pack_dword(L.bd, lane) : 0u, leaf_side, look);
                 if (STAMP && lane == 0) stp[9] = __builtin_amdgcn_s_memtime();
                 return;
             }
