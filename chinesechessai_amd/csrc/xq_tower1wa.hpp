@@ -327,8 +327,13 @@ __global__ __launch_bounds__(256, 1) void k_tower1wa(TowerArgs A)
                 dma16_buf_abs(wrsrc, (j & 1) ? wsrc_odd : wsrc_even, soff, (g & 3) * WBUF_BYTES + (wave * PPW + j) * 1024);
             }
     }
-    // epilogue of the input convolution (wave-local): acc -> bf16 -> ReLU -> LDS rows; tower layer 0 starts at bias[1]
-    {
+    // Round 5: with a tower behind it, the input convolution's epilogue is the assembly body's first drain - under tap 0 of
+    // layer 0, like every other layer boundary (tools/gen_tower1wa.py sec_pro) - and the statement starts right here: the
+    // accumulators hold conv + bias[0], stages 0..2 are in flight (its head waits for this wave's pieces, its first barrier
+    // publishes everybody's), bias[1] landed before the barrier above.  Without a tower (0 blocks) the heads read the
+    // input convolution's output: the HIP epilogue below.
+    if (nstages == 0) {
+        // epilogue of the input convolution (wave-local): acc -> bf16 -> ReLU -> LDS rows
         int ln;
         asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
         const int r = ln & 15, qq = ln >> 4;
@@ -346,9 +351,9 @@ __global__ __launch_bounds__(256, 1) void k_tower1wa(TowerArgs A)
         epi_pair<1, false>(seq6{}, acc, sb, tail_ok, lbq, nullptr);
         epi_pair<2, false>(seq6{}, acc, sb, tail_ok, lbq, nullptr);
         epi_pair<3, false>(seq6{}, acc, sb, tail_ok, lbq, nullptr);
-        await_lds();                                                   // the bias values are in the accumulators
+        await_lds();
+        barrier_dma();
     }
-    barrier_dma();                                                 // stages 0..2 and bias[1] have landed, for every wave
     stamp(2);
 
     // ---------------------------------------------------------------- residual tower: the assembly body

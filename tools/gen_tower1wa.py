@@ -780,11 +780,15 @@ def sec_head(stamps):
 
 
 def sec_pro(stamps):
+    """Round 5: the INPUT convolution's epilogue (HIP code until round 4: 4.8 k cycles of its own, followed by an unskewed tap 0
+    of layer 0 with cold fragment loads, 7.5 k) is the same drain as every odd layer's - accumulators -> bf16 -> ReLU -> LDS
+    rows, the next layer's bias row as the C operand of its tiles' first MFMAs - so it runs under tap 0 of layer 0 like every
+    other boundary (Emitter.skew with lt = -1, no lead-in: the input convolution has no weight stage of this ring to run its
+    head under).  The HIP code in front of the statement now ends behind the input convolution's MFMAs: the accumulators hold
+    conv + bias[0], the weight DMA of stages 0..2 is in flight (the head's vmcnt(0) covers this wave's pieces, the skew's
+    first barrier the other waves'), bias row 1 (layer 0) sits in bias slot 1."""
     e = Emitter(stamps)
-    e.comment("---- layer 0, tap 0 (nothing in front of it to run under)")
-    e.bias_dma(0, 1)
-    e.tap_regular(0, 0, 0, True, True)
-    e.stamp(3)            # (stamped build: the same vm-queue state at the loop head as behind the loop's own last stamp)
+    e.skew(-1, 0, 0, False, 1, 0, 1, False, 3)
     return e
 
 
@@ -953,27 +957,29 @@ def check_and_fill(linear, nblocks, verify=True):
         return True
 
     nlayers = 2 * nblocks
-    # LDS activation rows: content[J][n] = layer whose output is stored there (-1 = the input convolution's)
-    act = [[-1] * 6 for _ in range(4)]
-    # ring: slot -> (gstage, landed_for_all)
-    ring = {0: [0, True], 1: [1, True], 2: [2, True], 3: [None, True]}
+    # LDS activation rows: content[J][n] = layer whose output is stored there (-1 = the input convolution's, -2 = nothing yet:
+    # the statement starts behind the input convolution's MFMAs, its epilogue is the first drain)
+    act = [[-2] * 6 for _ in range(4)]
+    # ring: slot -> (gstage, landed_for_all).  Stages 0..2 were issued by the HIP code (4 pieces per wave each); the head's
+    # vmcnt(0) covers this wave's pieces, the first barrier publishes everybody's
+    ring = {0: [0, False], 1: [1, False], 2: [2, False], 3: [None, True]}
     ring_reads = {}            # gstage -> list of lds op indices of reads issued
     bias_slot = {0: [None, True, []], 1: [0, True, []]}      # slot -> [layer whose bias, landed for all, read op indices]
     frag = {}                  # slot / 'xf<n>' -> (tag, lds op index)
-    acc = {t: {"hist": [("BIAS", 0)], "read": set(), "last_mfma": -10 ** 9, "pending": None} for t in range(48)}
+    acc = {t: {"hist": [("BIAS", -1), ("INPUT",)], "read": set(), "last_mfma": -10 ** 9, "pending": None} for t in range(48)}
     biasreg = {}               # weight tile mt -> (layer whose bias row a[A_BIAS + 4 mt ..] holds, lds op index)
     rd = {}                    # vgpr -> (tile, comp, layer)
     pk = {}                    # vgpr -> ("cvt" | "relu", tile, comps, layer)
     nl, retired = 0, 0         # LDS queue
-    vq = []                    # vm queue entries: ("w", gstage, piece) | ("bias", slot) | ("st",)
+    vq = [("w", gs, j, -1) for gs in range(3) for j in range(4)]    # vm queue entries: ("w", gstage, piece) | ("bias", slot) | ("st",)
     vdone = 0                  # entries known complete (prefix), this wave's view WITHOUT the bias entries
     vq_nb = []                 # the same queue without bias entries (what waves 0, 2, 3 see)
-    vdone_nb = 0
-    vdone_w1 = 0               # wave 1's view (with its bias entries)
+    vdone_nb = 12              # (the head's vmcnt(0))
+    vdone_w1 = 12              # wave 1's view (with its bias entries)
     last_barrier = -1
     stores_since = {}          # bias slot read bookkeeping
     blk = 0
-    expected = {}
+    expected = {-1: [("BIAS", -1), ("INPUT",)]}
     for L in range(nlayers):
         h = [("BIAS", L)] + ([("skip", L)] if L & 1 else []) + [(L, tap, ks) for tap in range(9) for ks in range(4)]
         expected[L] = h
