@@ -184,6 +184,8 @@ def main():
                          "per GPU through the --games concurrent slots, a finished game's slot being refilled with the next seed")
     ap.add_argument("--profile-plies", type=int, default=0,
                     help="profiling aid only: stop every step after this many plies (the JSON line is then NOT a benchmark)")
+    ap.add_argument("--no-eval-cache", action="store_true",
+                    help="switch the evaluation cache (position -> priors + value, kept two plies) off")
     ap.add_argument("--no-leaf-dedupe", action="store_true",
                     help="every pending leaf gets its own network row (default: equal positions of a round share one; "
                          "value_no_dedupe reports this form beside the headline)")
@@ -381,9 +383,10 @@ def run_rank(args):
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     weights_equal = None
 
-    def make_ev(policy_columns, leaf_dedupe=True):
-        return TorchNetEvaluator(net, dtype=dtype, chunk=args.net_chunk or None, policy_columns=policy_columns,
-                                 fused_tower=bool(args.fused_tower), leaf_dedupe=leaf_dedupe)
+    def make_ev(policy_columns, leaf_dedupe=True, eval_cache=None, net_=None):
+        return TorchNetEvaluator(net_ if net_ is not None else net, dtype=dtype, chunk=args.net_chunk or None,
+                                 policy_columns=policy_columns, fused_tower=bool(args.fused_tower), leaf_dedupe=leaf_dedupe,
+                                 eval_cache=(not args.no_eval_cache) if eval_cache is None else eval_cache)
     ev = make_ev(args.policy_columns, not args.no_leaf_dedupe)
     if use_dist:
         # every rank's leaf evaluator reads the same bits: MIN / MAX all-reduce of a digest of the folded weights
@@ -470,6 +473,7 @@ def run_rank(args):
         eng.max_moves = saved
     sync()
     eng.row_history(cap=0, reset=True)
+    eng.eval_cache_stats(reset=True)
     eng.profile(True)
     tm.on(True)
     # shader clock held while the trunk kernel runs: one workgroup in 64 adds its cycles / 100 MHz ticks (xq_debug.h)
@@ -488,6 +492,7 @@ def run_rank(args):
     clk = clock_buf.cpu().numpy()
     trunk_clock_ghz = float(clk[0]) / float(clk[1]) * 0.1 if clk[1] > 0 else None
     prof = eng.profile_read()
+    ec_hits_timed = eng.eval_cache_stats(reset=True)[0] if eng.eval_cache else 0
     carry_on = eng._carry_on
     rows_hist, n_rounds = eng.row_history(reset=True) if eng.row_compaction else (None, 0)
     fw_t = np.array([a.elapsed_time(b) for a, b in tm.fw])
@@ -525,6 +530,38 @@ def run_rank(args):
             aux["value_full_policy_head"] = timed_steps(ev_all, 9_100_000)
             del ev_all
         del ev_nd
+        if ev.eval_cache:
+            # the evaluation cache (position -> priors + value, two plies): random-init priors are 0.35 % apart, a search
+            # never descends twice into the same child, nothing below the played move is expanded - the cache can answer next
+            # to nothing in the headline workload and costs its probe.  What it is for is a TRAINED network, whose search
+            # follows lines: the same architecture with the policy head's weights and bias scaled by 256 (seeded random-init
+            # otherwise: the top move then holds ~0.9 of the prior mass), with the cache and without
+            import copy
+            ev_nc = make_ev(args.policy_columns, ev.leaf_dedupe, eval_cache=False)
+            step(eng, ev_nc, 10_000_000)
+            aux["value_no_eval_cache"] = timed_steps(ev_nc, 10_100_000)
+            del ev_nc
+            net_pk = copy.deepcopy(net)
+            with torch.no_grad():
+                net_pk.policy_fc.weight.mul_(256.0)
+                net_pk.policy_fc.bias.mul_(256.0)
+            for key, cache in (("value_peaked_priors", True), ("value_peaked_priors_no_reuse", False)):
+                ev_pk = make_ev(args.policy_columns, ev.leaf_dedupe, eval_cache=cache, net_=net_pk)
+                step(eng, ev_pk, 11_000_000)
+                eng.eval_cache_stats(reset=True)
+                eng.row_history(cap=0, reset=True)
+                aux[key] = timed_steps(ev_pk, 11_100_000)
+                rows_pk, _ = eng.row_history(reset=True)
+                aux[key + "_rows_per_game"] = float(rows_pk.astype(np.int64).sum()) / (TG * args.aux_steps)
+                if cache:
+                    hits, fills = eng.eval_cache_stats(reset=True)
+                    aux["peaked_priors_cache_hits_per_game"] = hits / float(TG * args.aux_steps)
+                del ev_pk
+            del net_pk
+            aux["peaked_priors_note"] = ("the same workload with the policy head scaled by 256 (policy_fc.weight and .bias of the "
+                                         "seeded random-init network x 256: peaked priors, a stand-in for a trained network); "
+                                         "value_peaked_priors = everything on, value_peaked_priors_no_reuse = the evaluation cache "
+                                         "off; rows_per_game = network rows evaluated per game")
         aux["aux_note"] = ("games/s over %d extra steps each, same engine, outside the timed region: value_no_dedupe = every "
                            "pending leaf has its own network row (carry-over on; the round-3a form); value_no_carry = that and "
                            "every root evaluated afresh, i.e. the reference's evaluation count, 7 forwards of G rows per ply "
@@ -619,6 +656,11 @@ def run_rank(args):
                           "position share one network row - every game starts from the same position with the same weights, so "
                           "the first plies of a step repeat across games: %d rows evaluated in this run of %d forwards; value_no_dedupe is "
                           "the figure with one row per pending leaf)" % (int(rows_fw.sum()), n_fw))
+        if eng.eval_cache:
+            extras.append("; evaluation cache ON (result-identical, tested: a position's priors and value are kept for two plies and "
+                          "answer for any later leaf that is the same position; %d leaves answered in this run - random-init priors "
+                          "make the search revisit next to nothing; value_no_eval_cache is the figure without it, "
+                          "value_peaked_priors / _no_reuse show what it is for)" % ec_hits_timed)
         if args.tree_reuse:
             extras.append(", tree reuse (extension)")
         if args.virtual_loss:

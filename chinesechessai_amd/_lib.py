@@ -170,6 +170,8 @@ _SIGNATURES = {
     "xq_engine_roots_not_ready": (C.c_int, [C.c_void_p, C.c_void_p]),
     "xq_engine_set_row_compaction": (C.c_int, [C.c_void_p, C.c_int]),
     "xq_engine_set_leaf_dedupe": (C.c_int, [C.c_void_p, C.c_int]),
+    "xq_engine_set_eval_cache": (C.c_int, [C.c_void_p, C.c_int]),
+    "xq_engine_eval_cache_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "xq_engine_row_map": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     "xq_engine_read_row_history": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.c_int]),
     "xq_engine_read_leaf_rows": (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -93,6 +93,18 @@ struct Eng {
     uint8_t *leaf_dup;        // [slots] 1 = a lower slot holds the same position (cleared by k_assign_rows after reading)
     float    *priors;         // [slots][128]
     double   *values;         // [slots]
+    // evaluation cache (xq_engine_set_eval_cache): the evaluator's answer - legal-move priors and value - for a position
+    // (board + side to move = everything the network reads, neural_network.py:128-146) is kept for two plies and handed to
+    // any later leaf that is the same position: no network row.  ec_state[i] = epoch << 32 | launch that filled the entry
+    // (0xffffffff: reserved, being filled); ec_key[i] = 12 board dwords, side + 2, n, value bits, 0; ec_prior[i][128].
+    // leaf_ec[slot]: -1 nothing, >= 0 the entry this pending leaf reads, <= -2 the entry -(i + 2) it fills when consumed
+    int ec_on, ec_mask;
+    unsigned ec_epoch, ec_seq;
+    unsigned long long *ec_state;
+    uint32_t *ec_key;
+    float    *ec_prior;
+    int32_t  *leaf_ec;
+    unsigned long long *ec_stats;     // [2] hits, fills
     // ---- per ply
     double temperature;
     uint64_t *pos_hist;       // [G][PATH_CAP]
@@ -112,6 +124,8 @@ struct Eng {
     int vloss, leaf_slots;
     uint8_t *nVl;
 };
+
+__device__ __forceinline__ void eval_cache_fill(const Eng &E, int i, uint32_t board_dword, int side, int n, float p0, float p1, float value);
 
 struct __align__(16) WaveLds {
     int8_t   root_bd[96];
@@ -363,7 +377,13 @@ __device__ void consume_eval(const Eng &E, int g, int slot, WaveLds &L, const Tr
     double v;
     float p0 = 0.f, p1 = 0.f;
     const int m0 = lane < n ? lm[lane] : 0, m1 = lane + 64 < n ? lm[lane + 64] : 0;
-    if (eval_kind == XQ_EVAL_PRIORS) {
+    const int ec = E.ec_on ? uni(E.leaf_ec[slot]) : -1;      // evaluation cache: >= 0 it answers, <= -2 this wave fills entry -(ec + 2)
+    if (ec >= 0) {
+        const float *pr = E.ec_prior + (size_t)ec * MAXM;
+        if (lane < n) p0 = pr[lane];
+        if (lane + 64 < n) p1 = pr[lane + 64];
+        v = (double)__uint_as_float(E.ec_key[(size_t)ec * 16 + 14]);
+    } else if (eval_kind == XQ_EVAL_PRIORS) {
         const float *pr = reinterpret_cast<const float *>(ev_a) + (size_t)slot * MAXM;
         if (lane < n) p0 = pr[lane];
         if (lane + 64 < n) p1 = pr[lane + 64];
@@ -394,6 +414,8 @@ __device__ void consume_eval(const Eng &E, int g, int slot, WaveLds &L, const Tr
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d, 64);
         p0 = e0 / sum; p1 = e1 / sum;
+        if (ec <= -2)
+            eval_cache_fill(E, -ec - 2, lane < 12 ? E.leaf_board[(size_t)slot * 12 + lane] : 0u, E.leaf_side[slot], n, p0, p1, (float)v);
     }
     if (E.noise_eps > 0.0 && node == root) root_noise(E, g, ply, n, p0, p1);
     const int first = (int)E.n_nodes[g];
@@ -516,22 +538,11 @@ __global__ __launch_bounds__(64) void k_set_roots(Eng E, const int8_t *boards, c
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
 #error "dedupe_insert: cross-XCD visibility rests on gfx950's lowering of relaxed agent-scope atomics (write-through / L2 bypass) and on the gfx9 s_waitcnt encoding; validate before building for another target"
 #endif
-struct DedupeLook {            // what dedupe_prepare hands to dedupe_finish
-    unsigned pos;
-    unsigned long long ent;
-};
-
-// first half: publish the leaf's board and side (past the L2s), hash the position, take a first look at its table entry.
-// Nothing of this wave enters the table here: the caller may do other work (move generation) while the stores land.
-__device__ __forceinline__ DedupeLook dedupe_prepare(const Eng &E, int slot, uint32_t my_dword /* lane < 12: packed board dword */, int side)
+// 64-bit hash of a position (12 packed board dwords, lane < 12, + side to move): wave-uniform.  Nothing trusts it: the
+// dedupe table and the evaluation cache compare boards in full.
+__device__ __forceinline__ uint64_t position_hash(uint32_t my_dword, int side)
 {
     const int lane = XQ_LANE;
-    // This leaf's board and side must be visible to every other wave before the table can hand them the slot.  The L2s of
-    // the 8 XCDs are not coherent with each other inside a kernel: an agent-scope release fence would write the whole L2
-    // back (measured: k_search_round 87 -> 320 us); instead the few words other waves read are stored and loaded with
-    // agent-scope atomics (write-through / L2 bypass) and only their completion is waited for (dedupe_finish).
-    if (lane < 12) __hip_atomic_store(&E.leaf_board[(size_t)slot * 12 + lane], my_dword, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (lane == 0) __hip_atomic_store(&E.leaf_side[slot], (int8_t)side, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     uint64_t h = 0;
     if (lane < 12) h = mix64(((uint64_t)(lane + 1) << 32) | my_dword);
 #pragma unroll
@@ -540,12 +551,84 @@ __device__ __forceinline__ DedupeLook dedupe_prepare(const Eng &E, int slot, uin
         h ^= ((uint64_t)hi << 32) | lo;
     }
     const uint32_t hlo = __builtin_amdgcn_readfirstlane((uint32_t)h), hhi = __builtin_amdgcn_readfirstlane((uint32_t)(h >> 32));
-    h = mix64((((uint64_t)hhi << 32) | hlo) ^ (0x9E3779B97F4A7C15ull * (uint64_t)(side + 2)));
+    return mix64((((uint64_t)hhi << 32) | hlo) ^ (0x9E3779B97F4A7C15ull * (uint64_t)(side + 2)));
+}
+
+// Evaluation cache, fill side: the wave that consumes a leaf whose probe reserved entry i writes the position, its priors
+// (before any root noise) and its value, then the state word.  Readers accept the entry from the next launch on.
+__device__ __forceinline__ void eval_cache_fill(const Eng &E, int i, uint32_t board_dword /* lane < 12 */, int side, int n,
+                                                float p0, float p1, float value)
+{
+    const int lane = XQ_LANE;
+    uint32_t k = board_dword;
+    if (lane == 12) k = (uint32_t)(side + 2);
+    else if (lane == 13) k = (uint32_t)n;
+    else if (lane == 14) k = __float_as_uint(value);
+    else if (lane == 15) k = 0u;
+    if (lane < 16) E.ec_key[(size_t)i * 16 + lane] = k;
+    if (lane < n) E.ec_prior[(size_t)i * MAXM + lane] = p0;
+    if (lane + 64 < n) E.ec_prior[(size_t)i * MAXM + 64 + lane] = p1;
+    if (lane == 0) {
+        E.ec_state[i] = ((unsigned long long)E.ec_epoch << 32) | E.ec_seq;
+        atomicAdd(&E.ec_stats[1], 1ull);
+    }
+}
+
+struct DedupeLook {            // what dedupe_prepare hands to dedupe_finish
+    unsigned pos;
+    unsigned long long ent;
+};
+
+// first half: publish the leaf's board and side (past the L2s), take a first look at the position's table entry.
+// Nothing of this wave enters the table here: the caller may do other work (move generation) while the stores land.
+__device__ __forceinline__ DedupeLook dedupe_prepare(const Eng &E, int slot, uint32_t my_dword /* lane < 12: packed board dword */, int side,
+                                                     uint64_t h)
+{
+    const int lane = XQ_LANE;
+    // This leaf's board and side must be visible to every other wave before the table can hand them the slot.  The L2s of
+    // the 8 XCDs are not coherent with each other inside a kernel: an agent-scope release fence would write the whole L2
+    // back (measured: k_search_round 87 -> 320 us); instead the few words other waves read are stored and loaded with
+    // agent-scope atomics (write-through / L2 bypass) and only their completion is waited for (dedupe_finish).
+    if (lane < 12) __hip_atomic_store(&E.leaf_board[(size_t)slot * 12 + lane], my_dword, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane == 0) __hip_atomic_store(&E.leaf_side[slot], (int8_t)side, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     DedupeLook k;
     k.pos = (unsigned)h & (unsigned)E.dd_mask;
     // the first look at the table travels together with the stores above (the look is only a hint: the CAS decides)
     k.ent = __hip_atomic_load(&E.dd_tab[k.pos], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return k;
+}
+
+// Evaluation cache, look-up side (called for a leaf about to wait for the network).  Returns the entry that holds this
+// position's evaluation (>= 0: no network row needed), or -(i + 2) after reserving entry i for it (the wave that consumes
+// the leaf fills it), or -1 (no luck: evaluated, not kept).  An entry is read only if it was filled in an EARLIER launch -
+// kernel boundaries make it visible, nothing inside a launch has to - and within the last two plies (the epoch): older
+// entries are free to be taken over, so the table needs no clearing and stays as small as two plies of evaluations.
+__device__ __forceinline__ int eval_cache_probe(const Eng &E, uint64_t h, uint32_t my_dword, int side)
+{
+    const int lane = XQ_LANE;
+    const unsigned mask = (unsigned)E.ec_mask, epoch = E.ec_epoch, seq = E.ec_seq;
+    unsigned pos = (unsigned)(h >> 24) & mask;
+    for (int probe = 0; probe < 4; probe++, pos = (pos + 1) & mask) {
+        const unsigned long long raw = E.ec_state[pos];
+        const unsigned long long st = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(raw >> 32)) << 32) |
+                                      __builtin_amdgcn_readfirstlane((uint32_t)raw);
+        const unsigned ep = (unsigned)(st >> 32), filled = (unsigned)st;
+        if (epoch - ep > 1u) {                                  // older than the ply before this one (or never used): take it
+            unsigned long long old = 0;
+            if (lane == 0) old = atomicCAS(&E.ec_state[pos], st, ((unsigned long long)epoch << 32) | 0xffffffffull);
+            old = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(old >> 32)) << 32) |
+                  __builtin_amdgcn_readfirstlane((uint32_t)old);
+            return old == st ? -(int)pos - 2 : -1;              // (lost the race: most likely to a wave with this very position)
+        }
+        if (filled >= seq) return -1;                           // reserved or filled in this launch: contents not visible yet
+        const uint32_t theirs = lane < 13 ? E.ec_key[(size_t)pos * 16 + lane] : 0u;
+        const uint32_t mine = lane < 12 ? my_dword : (uint32_t)(side + 2);
+        if (__ballot(lane < 13 && theirs != mine) == 0ull) {
+            if (lane == 0) atomicAdd(&E.ec_stats[0], 1ull);
+            return (int)pos;
+        }
+    }
+    return -1;
 }
 
 // second half: once the stores of dedupe_prepare have landed, enter the table
@@ -593,7 +676,7 @@ __device__ __forceinline__ void dedupe_finish(const Eng &E, int slot, uint32_t m
 
 __device__ __forceinline__ void dedupe_insert(const Eng &E, int slot, uint32_t my_dword /* lane < 12: packed board dword */, int side)
 {
-    dedupe_finish(E, slot, my_dword, side, dedupe_prepare(E, slot, my_dword, side));
+    dedupe_finish(E, slot, my_dword, side, dedupe_prepare(E, slot, my_dword, side, position_hash(my_dword, side)));
 }
 
 __device__ __forceinline__ void record_leaf(const Eng &E, int slot, WaveLds &L, const int8_t *bd, int side, int node,
@@ -614,7 +697,18 @@ __device__ __forceinline__ void record_leaf(const Eng &E, int slot, WaveLds &L, 
     }
     if (planes) write_planes(bd, side, planes, fmt, slot);
     if (st && lane == 0) st[8] = __builtin_amdgcn_s_memtime();
-    if (E.dedupe) dedupe_insert(E, slot, my_dword, side);     // (last: the planes' stores travel while it waits for the table)
+    const uint64_t h = (E.dedupe || E.ec_on) ? position_hash(my_dword, side) : 0ull;
+    int ec = -1;
+    if (E.ec_on) {
+        if (E.dedupe) {                                       // (the board must be there for the wave that fills the entry)
+            if (lane < 12) __hip_atomic_store(&E.leaf_board[(size_t)slot * 12 + lane], my_dword, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0) __hip_atomic_store(&E.leaf_side[slot], (int8_t)side, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        ec = eval_cache_probe(E, h, my_dword, side);
+        if (lane == 0) E.leaf_ec[slot] = ec;
+    }
+    // (last: the planes' stores travel while it waits for the table; a leaf the cache answers needs no row at all)
+    if (E.dedupe && ec < 0) dedupe_finish(E, slot, my_dword, side, dedupe_prepare(E, slot, my_dword, side, h));
     if (st && lane == 0) st[9] = __builtin_amdgcn_s_memtime();
 }
 
@@ -850,6 +944,10 @@ __device__ void search_round_one(const Eng &E, WaveLds &L, int round, int batch_
     int p_first = (int)E.n_nodes[g];
     const int m0 = E.leaf_moves[(size_t)slot * MAXM + lane], m1 = E.leaf_moves[(size_t)slot * MAXM + 64 + lane];
     const int pth = E.leaf_path[(size_t)slot * PATH_CAP + lane];
+    const int32_t *ec_p = E.ec_on ? E.leaf_ec + slot : reinterpret_cast<const int32_t *>(E.n_nodes + g);
+    const int ec_v = *ec_p;
+    const uint32_t lbw = lane < 12 ? E.leaf_board[(size_t)slot * 12 + lane] : 0u;      // (the pending leaf's position: key of the entry it fills)
+    const int lside = E.leaf_side[slot];
     int root = (round > 0 && E.tree_reuse) ? root_v : 0;
     int r_nc = T.nc[root], r_first = T.first[root];
     uint32_t r_N = T.N[root];
@@ -900,6 +998,7 @@ __device__ void search_round_one(const Eng &E, WaveLds &L, int round, int batch_
     r_nc = uni(r_nc); r_first = uni(r_first); r_N = (uint32_t)uni((int)r_N);
     p_node = uni(p_node); p_n = uni(p_n); p_mult = uni(p_mult); p_depth = uni(p_depth); p_row = uni(p_row); p_first = uni(p_first);
     const bool pending = p_node != LEAF_NONE;        // (round 0: never)
+    const int p_ec = E.ec_on ? uni(ec_v) : -1;       // >= 0: the evaluation cache answers for the pending leaf; <= -2: it fills entry -(p_ec + 2)
 
     // ---- (B): the root's children as they stand before this round's expansion / backup
     // (cM = move | n_child << 16 | flags << 24 of the child: what the descent needs of the child it picks)
@@ -927,7 +1026,13 @@ __device__ void search_round_one(const Eng &E, WaveLds &L, int round, int batch_
         if (lane < depth) L.path_node[lane] = (uint16_t)pth;
         double v;
         float p0 = 0.f, p1 = 0.f;
-        if (eval_kind == XQ_EVAL_PRIORS) {
+        if (p_ec >= 0) {
+            // the evaluation cache holds this position's priors and value (the same bits the network would return)
+            const float *pr = E.ec_prior + (size_t)p_ec * MAXM;
+            if (lane < n) p0 = pr[lane];
+            if (lane + 64 < n) p1 = pr[lane + 64];
+            v = (double)__uint_as_float(E.ec_key[(size_t)p_ec * 16 + 14]);
+        } else if (eval_kind == XQ_EVAL_PRIORS) {
             const float *pr = reinterpret_cast<const float *>(ev_a) + (size_t)slot * MAXM;
             if (lane < n) p0 = pr[lane];
             if (lane + 64 < n) p1 = pr[lane + 64];
@@ -958,6 +1063,7 @@ __device__ void search_round_one(const Eng &E, WaveLds &L, int round, int batch_
 #pragma unroll
             for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d, 64);
             p0 = e0 / sum; p1 = e1 / sum;
+            if (p_ec <= -2) eval_cache_fill(E, -p_ec - 2, lbw, lside, n, p0, p1, (float)v);
         }
         if (E.noise_eps > 0.0 && p_node == root) root_noise(E, g, gs.n_plies, n, p0, p1);
         const bool fits = p_first + n <= E.ncap;
@@ -1083,10 +1189,12 @@ __device__ void search_round_one(const Eng &E, WaveLds &L, int round, int batch_
             // past the L2s), its planes and the first look at its table entry leave before the move generation
             const int leaf_side = -st.side;
             uint32_t my_dword = 0;
+            uint64_t h = 0;
             DedupeLook look{ 0u, 0ull };
             auto early = [&](const int8_t *bd) {
                 my_dword = lane < 12 ? pack_dword(bd, lane) : 0u;
-                if (E.dedupe) look = dedupe_prepare(E, slot, my_dword, leaf_side);
+                if (E.dedupe || E.ec_on) h = position_hash(my_dword, leaf_side);
+                if (E.dedupe) look = dedupe_prepare(E, slot, my_dword, leaf_side, h);
                 else {
                     if (lane < 12) E.leaf_board[(size_t)slot * 12 + lane] = my_dword;
                     if (lane == 0) E.leaf_side[slot] = (int8_t)leaf_side;
@@ -1108,7 +1216,13 @@ __device__ void search_round_one(const Eng &E, WaveLds &L, int round, int batch_
                 if (lane < depth) E.leaf_path[(size_t)slot * PATH_CAP + lane] = L.path_node[lane];
                 if (STAMP && lane == 0) stp[8] = __builtin_amdgcn_s_memtime();
                 // (the packed board again from LDS: cheaper than a register held across the move generation)
-                if (E.dedupe) dedupe_finish(E, slot, lane < 12 ? pack_dword(L.bd, lane) : 0u, leaf_side, look);
+                const uint32_t bdw = lane < 12 ? pack_dword(L.bd, lane) : 0u;
+                int ec = -1;
+                if (E.ec_on) {
+                    ec = eval_cache_probe(E, h, bdw, leaf_side);
+                    if (lane == 0) E.leaf_ec[slot] = ec;
+                }
+                if (E.dedupe && ec < 0) dedupe_finish(E, slot, bdw, leaf_side, look);
                 if (STAMP && lane == 0) stp[9] = __builtin_amdgcn_s_memtime();
                 return;
             }
@@ -1201,6 +1315,22 @@ __global__ __launch_bounds__(1024) void k_assign_rows(Eng E, int n_slots, unsign
         for (int i = 0; i < 16; i++) {
             const uint32_t v = (i & 1) ? w[i >> 1] >> 16 : w[i >> 1] & 0xffffu;
             if (v != LEAF_NONE) flags |= 1u << i;
+        }
+        if (E.ec_on) {
+            // a pending leaf the evaluation cache answers (leaf_ec >= 0) needs no row
+            uint32_t cached = 0;
+            if (s0 + 16 <= n_slots) {
+#pragma unroll
+                for (int i4 = 0; i4 < 4; i4++) {
+                    const int4 c = reinterpret_cast<const int4 *>(E.leaf_ec + s0)[i4];
+                    cached |= (c.x >= 0 ? 1u : 0u) << (4 * i4) | (c.y >= 0 ? 2u : 0u) << (4 * i4) | (c.z >= 0 ? 4u : 0u) << (4 * i4) |
+                              (c.w >= 0 ? 8u : 0u) << (4 * i4);
+                }
+            } else {
+                for (int i = 0; i < 16; i++)
+                    if (s0 + i < n_slots && E.leaf_ec[s0 + i] >= 0) cached |= 1u << i;
+            }
+            flags &= ~cached;
         }
         uint32_t dups = 0;                                   // bit i: pending, but a lower slot holds the same position
         if (E.dedupe) {
@@ -1858,6 +1988,7 @@ struct xq_engine {
     unsigned row_seq = 0;                     // search rounds launched with row compaction (index into row_hist)
     bool row_map_fetched = false;             // xq_engine_row_map since row compaction was last switched: the evaluator knows the layout
     unsigned dd_tag = 0;                      // round tag of the leaf dedupe table (never 0: the cleared table's tag)
+    unsigned ec_epoch = 16, ec_seq = 0;       // evaluation cache: ply counter (+2 at every new set of roots), launch counter
     // profiling
     bool prof = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_search, ev_play;
@@ -2037,6 +2168,7 @@ extern "C" int xq_engine_new_games(xq_engine *e, const uint32_t *seeds)
     HIPCHK(hipMemcpyAsync(e->E.uniforms, u.data(), u.size() * 8, hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));          // u is a local: copy must finish
     if (e->E.eval_carry) HIPCHK(hipMemsetAsync(e->E.roots_not_ready, 0, 4, e->stream));
+    e->ec_epoch += 2;                                                    // new games, possibly new weights: nothing cached survives
     hipLaunchKernelGGL(k_new_games, dim3(e->E.G), dim3(64), 0, e->stream, e->E);
     HIPCHK(hipGetLastError());
     return 0;
@@ -2203,6 +2335,7 @@ extern "C" int xq_engine_set_roots(xq_engine *e, const int8_t *boards, const int
     HIPCHK(hipMemcpyAsync(e->stage_state, state, G * XQ_STATE_WORDS * 4, hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     if (e->E.eval_carry) HIPCHK(hipMemsetAsync(e->E.roots_not_ready, 0, 4, e->stream));     // k_set_roots counts them
+    e->ec_epoch += 2;
     hipLaunchKernelGGL(k_set_roots, dim3(e->E.G), dim3(64), 0, e->stream, e->E, e->stage_boards, e->stage_state);
     HIPCHK(hipGetLastError());
     return 0;
@@ -2276,6 +2409,7 @@ extern "C" int xq_engine_search_round(xq_engine *e, int round, int eval_kind, co
         if (ev) HIPCHK(hipEventRecord(ev->first, e->stream));
     }
     const int fmt = planes ? e->cfg.planes_format : XQ_PLANES_NONE;
+    e->E.ec_epoch = e->ec_epoch; e->E.ec_seq = ++e->ec_seq;
     if (e->E.dedupe) {                                                    // a fresh tag for this round's table entries
         if (++e->dd_tag == 0) {                                           // tag wrap: start from a cleared table
             HIPCHK(hipMemsetAsync(e->E.dd_tab, 0, ((size_t)e->E.dd_mask + 1) * 8, e->stream));
@@ -2345,6 +2479,45 @@ extern "C" int xq_engine_set_leaf_dedupe(xq_engine *e, int enable)
     return 0;
 }
 
+// Evaluation cache (default off): see Eng::ec_state.  log2_entries = 0 switches it off; otherwise the table has
+// 2^log2_entries entries of 576 B (16 <= log2_entries <= 24; two plies of evaluations should fill it to a half at most).
+// Result-identical for a deterministic evaluator whose answer depends on the position only (the caller vouches for that,
+// as for the leaf dedupe); entries live for two plies and never survive xq_engine_new_games / set_roots / refill_begin.
+extern "C" int xq_engine_set_eval_cache(xq_engine *e, int log2_entries)
+{
+    if (!e) return fail(XQ_E_INVALID, "null engine");
+    if (log2_entries == 0) { e->E.ec_on = 0; return 0; }
+    if (log2_entries < 10 || log2_entries > 24) return fail(XQ_E_INVALID, "eval cache: 10 <= log2_entries <= 24");
+    HIPCHK(hipSetDevice(e->cfg.device));
+    const size_t n = (size_t)1 << log2_entries;
+    if (!e->E.ec_state || (size_t)e->E.ec_mask + 1 != n) {
+        HIPCHK(hipStreamSynchronize(e->stream));
+        int bad = dalloc(e, e->E.ec_state, n);
+        bad |= dalloc(e, e->E.ec_key, n * 16); bad |= dalloc(e, e->E.ec_prior, n * MAXM);
+        if (!e->E.leaf_ec) bad |= dalloc(e, e->E.leaf_ec, (size_t)e->E.G * 64);
+        if (!e->E.ec_stats) bad |= dalloc(e, e->E.ec_stats, (size_t)2);
+        if (bad) return fail(XQ_E_HIP, "hipMalloc failed for the evaluation cache");
+        HIPCHK(hipMemsetAsync(e->E.leaf_ec, 0xff, (size_t)e->E.G * 64 * 4, e->stream));
+        e->E.ec_mask = (int)(n - 1);
+    }
+    e->ec_epoch += 2;
+    e->E.ec_on = 1;
+    return 0;
+}
+
+// hits / fills since the last reset (diagnostic of the evaluation cache)
+extern "C" int xq_engine_eval_cache_stats(xq_engine *e, uint64_t *hits_fills_host /*[2]*/, int reset)
+{
+    if (!e || !hits_fills_host) return fail(XQ_E_INVALID, "null argument");
+    hits_fills_host[0] = hits_fills_host[1] = 0;
+    if (!e->E.ec_stats) return 0;
+    HIPCHK(hipSetDevice(e->cfg.device));
+    HIPCHK(hipMemcpyAsync(hits_fills_host, e->E.ec_stats, 16, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if (reset) HIPCHK(hipMemsetAsync(e->E.ec_stats, 0, 16, e->stream));
+    return 0;
+}
+
 extern "C" int xq_engine_row_map(xq_engine *e, const int32_t **row_src_dev, const int32_t **row_count_dev)
 {
     if (!e || !row_src_dev || !row_count_dev) return fail(XQ_E_INVALID, "null argument");
@@ -2401,6 +2574,7 @@ extern "C" int xq_engine_end_search(xq_engine *e, int eval_kind, const void *ev_
     if (eval_kind != XQ_EVAL_PRIORS && e->E.compact && !e->row_map_fetched)
         return fail(XQ_E_INVALID, "logits handed in by slot while row compaction is on: fetch xq_engine_row_map or switch it off");
     HIPCHK(hipSetDevice(e->cfg.device));
+    e->E.ec_epoch = e->ec_epoch; e->E.ec_seq = ++e->ec_seq;
     hipLaunchKernelGGL(k_end_search, dim3(e->E.G), dim3(64), 0, e->stream, e->E, eval_kind, ev_a, ev_v);
     HIPCHK(hipGetLastError());
     return 0;
@@ -2416,6 +2590,7 @@ extern "C" int xq_engine_play_move(xq_engine *e)
         if (ev) HIPCHK(hipEventRecord(ev->first, e->stream));
     }
     if (e->E.eval_carry) HIPCHK(hipMemsetAsync(e->E.roots_not_ready, 0, 4, e->stream));
+    e->ec_epoch += 1;                                                    // the evaluation cache keeps two plies
     hipLaunchKernelGGL(k_play_move, dim3(e->E.G), dim3(64), 0, e->stream, e->E);
     HIPCHK(hipGetLastError());
     if (ev) HIPCHK(hipEventRecord(ev->second, e->stream));
@@ -2492,6 +2667,8 @@ extern "C" int xq_engine_refill_begin(xq_engine *e, const uint32_t *seeds, int t
     HIPCHK(hipMemsetAsync(e->out_gs, 0, T * sizeof(GameS), e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));          // locals: the copies must finish
     if (e->E.eval_carry) HIPCHK(hipMemsetAsync(e->E.roots_not_ready, 0, 4, e->stream));
+    e->ec_epoch += 2;                                                    // new games, possibly new weights: nothing cached survives
+    e->ec_epoch += 2;
     hipLaunchKernelGGL(k_new_games, dim3(e->E.G), dim3(64), 0, e->stream, e->E);
     HIPCHK(hipGetLastError());
     return 0;

@@ -86,7 +86,7 @@ class TorchNetEvaluator:
     deterministic = True
 
     def __init__(self, net, dtype=None, channels_last=True, chunk=None, policy_columns="reachable", fused_tower=True,
-                 leaf_dedupe=True):
+                 leaf_dedupe=True, eval_cache=True):
         import torch
         from .neural_network import InferenceNet
         self.torch = torch
@@ -111,6 +111,9 @@ class TorchNetEvaluator:
         # the hand-written kernels' output for a position is one fixed fp32 chain per element, whatever the row,
         # the batch size and the launch: equal positions may share a row
         self.leaf_dedupe = bool(leaf_dedupe and self.row_compaction)
+        # ... and a position evaluated during the last two plies - by any game - need not be evaluated again
+        # (SelfPlayEngine.set_eval_cache; `eval_cache=False` evaluates every leaf the reference would)
+        self.eval_cache = bool(eval_cache and self.row_compaction)
         self.row_src = self.n_rows_dev = None
 
     def bind(self, engine):
@@ -118,6 +121,7 @@ class TorchNetEvaluator:
         engine.set_row_compaction(self.row_compaction)
         if self.row_compaction:
             engine.set_leaf_dedupe(self.leaf_dedupe)
+            engine.set_eval_cache(self.eval_cache)
         self.row_src, self.n_rows_dev = engine.row_map()
         G = engine.n_rows                                       # one row per pending-leaf slot
         if self.channels_last:
@@ -212,6 +216,7 @@ class SelfPlayEngine:
         self._carry_on = False
         self.row_compaction = False
         self.leaf_dedupe = False
+        self.eval_cache = False
         self._noise = self._vloss = False
         self.tree_reuse = False
         if stream is not None:
@@ -302,6 +307,31 @@ class SelfPlayEngine:
         on the position only; the reference evaluates every leaf of every game (self_play.py:137-143)."""
         _lib.check(self.L.xq_engine_set_leaf_dedupe(self.h, 1 if enable else 0))
         self.leaf_dedupe = bool(enable)
+
+    def set_eval_cache(self, enable=True, log2_entries=None):
+        """Evaluation cache (xq_engine_set_eval_cache): the evaluator's priors and value for a position are kept in HBM for
+        two plies; a later pending leaf that is the same position - in any game - takes them from there instead of
+        becoming an evaluator row.  What it removes: the reference rebuilds its tree every ply (self_play.py:98), so
+        whatever the last ply's search expanded below the move that was played is evaluated again; with a trained
+        (peaked) network that is most of a ply's rows, with random-init weights next to nothing.  Result-identical for an
+        evaluator whose output depends on the position only; evaluators on the hand-written kernels switch it on when
+        they are bound (`TorchNetEvaluator(eval_cache=False)` keeps it off).  The default size holds four plies of
+        evaluations."""
+        if not enable:
+            _lib.check(self.L.xq_engine_set_eval_cache(self.h, 0))
+            self.eval_cache = False
+            return
+        if log2_entries is None:
+            want = 4 * self.rounds * self.n_rows
+            log2_entries = min(22, max(12, int(np.ceil(np.log2(max(want, 2))))))
+        _lib.check(self.L.xq_engine_set_eval_cache(self.h, int(log2_entries)))
+        self.eval_cache = True
+
+    def eval_cache_stats(self, reset=False):
+        """(hits, fills) of the evaluation cache since the last reset."""
+        out = np.zeros(2, np.uint64)
+        _lib.check(self.L.xq_engine_eval_cache_stats(self.h, _lib.ptr(out), 1 if reset else 0))
+        return int(out[0]), int(out[1])
 
     def row_map(self):
         """(row_src, row_count) device pointers as ints, or (None, None) without compaction."""
@@ -431,12 +461,15 @@ class SelfPlayEngine:
             raise _lib.XqError("the two evaluators of a match must use the same row layout and policy columns "
                                "(same dtype / layout / chunk / policy_columns / leaf_dedupe)")
         self.set_row_compaction(False)
+        self.set_eval_cache(False)
         for ev in (evaluator, opponent_evaluator):
             if ev is not None and self._row_layout(ev) is None:
                 ev.bind(self)                 # (by-slot priors first: they do not touch the layout)
         for ev in (evaluator, opponent_evaluator):
             if ev is not None and self._row_layout(ev) is not None:
                 ev.bind(self)
+        if opponent_evaluator is not None:
+            self.set_eval_cache(False)        # two networks answer differently for one position
 
     def play(self, evaluator, seeds, opponent_evaluator=None, uniforms=None, check_every=8, read=True,
              temperature_schedule=None):

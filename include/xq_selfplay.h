@@ -296,6 +296,20 @@ int  xq_engine_read_leaf_rows(xq_engine *e, int32_t *rows_host /* [G * leaf_slot
  * switching compaction off switches this off. */
 int  xq_engine_set_leaf_dedupe(xq_engine *e, int enable);
 
+/* Evaluation cache (off until asked for): the evaluator's answer for a position - the priors of its legal moves and its
+ * value - is kept in a table in HBM (2^log2_entries entries of 576 B, 10 <= log2_entries <= 24; 0 switches it off) for
+ * two plies, and a later pending leaf that is the same position (board and side to move compared in full) takes it from
+ * there: no evaluator row.  The reference has no counterpart: it rebuilds its tree every ply (self_play.py:98) and
+ * evaluates again what the ply before expanded below the move that was played, and its workers share nothing
+ * (self_play.py:137-143).  Result-identical whenever the evaluator's output for a position depends on nothing else -
+ * the caller vouches for that, as for the leaf dedupe (true of xq_tower_nhwc_bf16 + xq_policy_fc_bf16 +
+ * xq_value_head_bf16: one fixed fp32 chain per output element whatever the row and the launch).  An entry is used from
+ * the launch after the one that filled it; xq_engine_new_games / set_roots / refill_begin age every entry out (new
+ * weights must come with one of them).  Works with XQ_EVAL_LOGITS_* output; priors handed in by slot are not cached.
+ * xq_engine_eval_cache_stats: hits and fills since the last reset (diagnostic). */
+int  xq_engine_set_eval_cache(xq_engine *e, int log2_entries);
+int  xq_engine_eval_cache_stats(xq_engine *e, uint64_t *hits_fills_host /* [2] */, int reset);
+
 /* ---- refill: `total` games through the engine's G concurrent slots, a finished game's slot being restarted
  * on the next unplayed game at once — what the reference's pool does by construction (imap_unordered hands a
  * worker its next game as soon as one ends, self_play.py:404-408).  A game's result depends only on

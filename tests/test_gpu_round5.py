@@ -184,3 +184,66 @@ def test_auto_carry_needs_row_compaction(L):
     assert eng._carry_on
     eng.close()
     assert np.array_equal(a.chosen, b.chosen) and np.array_equal(a.s_counts, b.s_counts)
+
+
+def test_eval_cache_is_result_identical_and_answers_for_peaked_priors(L):
+    """evaluation reuse below the root.  The reference rebuilds its tree every ply (self_play.py:98)
+    and evaluates again what the last ply's search expanded below the move that was played; the engine's evaluation cache
+    (xq_engine_set_eval_cache: position -> priors + value, kept for two plies, shared by all games) answers those leaves
+    without a network row.  1,024 games x S = 50 with the mate-line network (peaked priors: a search follows one line, so
+    the next ply meets its own expansions again): every game's records must equal, field for field and z bit for bit, the
+    PLAIN path (no cache, no dedupe, no carry-over), with the cache alone and with everything on; the cache must really
+    answer (hits, fewer evaluator rows); and a cached engine must not carry anything over to a second network."""
+    import torch
+    from chinesechessai_amd import distributed as xd
+    from chinesechessai_amd.engine import SelfPlayEngine, TorchNetEvaluator
+    G, S = 1024, 50
+    net = _mate_line_net(2, 11)
+    seeds = (np.arange(G, dtype=np.uint32) * 5 + 1).astype(np.uint32)
+    block = 70 * xd.RECORD_BYTES
+
+    def run(net_, dedupe, cache, carry):
+        ev = TorchNetEvaluator(net_, leaf_dedupe=dedupe, eval_cache=cache)
+        eng = SelfPlayEngine(G, sims=S, planes_format=ev.planes_format)
+        if not carry:
+            eng.set_root_eval_carry(False)
+        eng.play(ev, seeds, read=False)
+        assert eng.eval_cache == cache and eng.leaf_dedupe == dedupe and eng._carry_on == carry
+        t = torch.zeros(G * block, dtype=torch.uint8, device="cuda")
+        eng.pack_samples(t.data_ptr())
+        out = eng.read_game_outcomes()
+        rows, n_rounds = eng.row_history()
+        stats = eng.eval_cache_stats()
+        eng.close()
+        return xd.records_to_numpy(t).reshape(G, 70), out, int(rows.astype(np.int64).sum()), stats
+
+    ref, ref_out, rows_plain, st0 = run(net, False, False, False)
+    assert st0 == (0, 0) and int(ref_out["error"].sum()) == 0
+    assert (ref_out["n_plies"] < 70).sum() >= G // 20                                  # the network ends games early, too
+    for dedupe, cache, carry in ((False, True, False), (True, True, True)):
+        rec, out, rows, (hits, fills) = run(net, dedupe, cache, carry)
+        for k in ("winner", "reason", "reason_side", "reason_count", "n_plies", "n_samples", "error"):
+            assert np.array_equal(out[k], ref_out[k]), (k, dedupe, cache, carry)
+        for g in range(G):
+            _same_game(rec[g], ref[g], (g, dedupe, cache, carry))
+        assert hits > 0 and fills > 0, (hits, fills)
+        if not dedupe:
+            # the cache alone: every hit is a row the plain path evaluated
+            assert rows == rows_plain - hits, (rows, rows_plain, hits)
+            print("eval cache alone: %d rows without it, %d hits, %d fills" % (rows_plain, hits, fills))
+            assert hits > rows_plain // 20, (hits, rows_plain)                          # peaked priors: a real share of the rows
+        else:
+            assert rows < rows_plain - hits // 2
+    # other weights, same engine object semantics: a fresh engine per evaluator in this test; inside ONE engine new games
+    # age the cache out (xq_engine_new_games), so a second network never reads the first one's answers
+    net2 = _mate_line_net(2, 12)
+    ev1, ev2 = TorchNetEvaluator(net), TorchNetEvaluator(net2)
+    eng = SelfPlayEngine(64, sims=S, planes_format=ev1.planes_format, max_moves=6)
+    a1 = eng.play(ev1, seeds[:64])
+    b2 = eng.play(ev2, seeds[:64])
+    eng.close()
+    eng = SelfPlayEngine(64, sims=S, planes_format=ev2.planes_format, max_moves=6)
+    b2_fresh = eng.play(ev2, seeds[:64])
+    eng.close()
+    assert np.array_equal(b2.s_counts, b2_fresh.s_counts) and np.array_equal(b2.chosen, b2_fresh.chosen)
+    assert not np.array_equal(a1.s_counts, b2.s_counts)
