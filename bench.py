@@ -554,7 +554,7 @@ def run_rank(args):
                 rows_pk, _ = eng.row_history(reset=True)
                 aux[key + "_rows_per_game"] = float(rows_pk.astype(np.int64).sum()) / (TG * args.aux_steps)
                 if cache:
-                    hits, fills = eng.eval_cache_stats(reset=True)
+                    hits, fills, _ = eng.eval_cache_stats(reset=True)
                     aux["peaked_priors_cache_hits_per_game"] = hits / float(TG * args.aux_steps)
                 del ev_pk
             del net_pk

@@ -104,7 +104,8 @@ struct Eng {
     uint32_t *ec_key;
     float    *ec_prior;
     int32_t  *leaf_ec;
-    unsigned long long *ec_stats;     // [2] hits, fills
+    uint32_t *ec_stats;               // [3][G * 64] per slot: hits, fills, mismatches found in verify mode (ec_on == 2)
+    int ec_stat_stride;
     // ---- per ply
     double temperature;
     uint64_t *pos_hist;       // [G][PATH_CAP]
@@ -126,6 +127,19 @@ struct Eng {
 };
 
 __device__ __forceinline__ void eval_cache_fill(const Eng &E, int i, uint32_t board_dword, int side, int n, float p0, float p1, float value);
+// (accessors of the evaluation cache: past the L2s - see eval_cache_fill)
+__device__ __forceinline__ uint32_t ec_ld(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void ec_st(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned long long ec_ld64(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void ec_st64(unsigned long long *p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float ec_ldf(const float *p) { return __uint_as_float(ec_ld(reinterpret_cast<const uint32_t *>(p))); }
+// a 64-bit value of the first active lane, wave-uniform.  (__builtin_amdgcn_readfirstlane returns int: without the casts the
+// low half is SIGN-extended into the high one - a state word that ends in 0xffffffff then reads as all ones.)
+__device__ __forceinline__ unsigned long long uni64(unsigned long long v)
+{
+    return ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32) |
+           (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+}
 
 struct __align__(16) WaveLds {
     int8_t   root_bd[96];
@@ -378,11 +392,12 @@ __device__ void consume_eval(const Eng &E, int g, int slot, WaveLds &L, const Tr
     float p0 = 0.f, p1 = 0.f;
     const int m0 = lane < n ? lm[lane] : 0, m1 = lane + 64 < n ? lm[lane + 64] : 0;
     const int ec = E.ec_on ? uni(E.leaf_ec[slot]) : -1;      // evaluation cache: >= 0 it answers, <= -2 this wave fills entry -(ec + 2)
-    if (ec >= 0) {
+    if (ec >= 0 && E.ec_on == 1) {
         const float *pr = E.ec_prior + (size_t)ec * MAXM;
-        if (lane < n) p0 = pr[lane];
-        if (lane + 64 < n) p1 = pr[lane + 64];
-        v = (double)__uint_as_float(E.ec_key[(size_t)ec * 16 + 14]);
+        if (lane < n) p0 = ec_ldf(pr + lane);
+        if (lane + 64 < n) p1 = ec_ldf(pr + lane + 64);
+        v = (double)__uint_as_float(ec_ld(&E.ec_key[(size_t)ec * 16 + 14]));
+        if (lane == 0) E.ec_stats[slot] += 1u;
     } else if (eval_kind == XQ_EVAL_PRIORS) {
         const float *pr = reinterpret_cast<const float *>(ev_a) + (size_t)slot * MAXM;
         if (lane < n) p0 = pr[lane];
@@ -414,8 +429,17 @@ __device__ void consume_eval(const Eng &E, int g, int slot, WaveLds &L, const Tr
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d, 64);
         p0 = e0 / sum; p1 = e1 / sum;
-        if (ec <= -2)
+        if (ec <= -2) {
             eval_cache_fill(E, -ec - 2, lane < 12 ? E.leaf_board[(size_t)slot * 12 + lane] : 0u, E.leaf_side[slot], n, p0, p1, (float)v);
+            if (lane == 0) E.ec_stats[E.ec_stat_stride + slot] += 1u;
+        } else if (ec >= 0) {                                 // verify mode
+            const float *pr = E.ec_prior + (size_t)ec * MAXM;
+            const bool bad = (lane < n && __float_as_uint(ec_ldf(pr + lane)) != __float_as_uint(p0)) ||
+                             (lane + 64 < n && __float_as_uint(ec_ldf(pr + lane + 64)) != __float_as_uint(p1)) ||
+                             ec_ld(&E.ec_key[(size_t)ec * 16 + 14]) != __float_as_uint((float)v) || ec_ld(&E.ec_key[(size_t)ec * 16 + 13]) != (uint32_t)n;
+            const bool any = __ballot(bad) != 0ull;
+            if (lane == 0) { E.ec_stats[slot] += 1u; if (any) E.ec_stats[2 * E.ec_stat_stride + slot] += 1u; }
+        }
     }
     if (E.noise_eps > 0.0 && node == root) root_noise(E, g, ply, n, p0, p1);
     const int first = (int)E.n_nodes[g];
@@ -554,6 +578,9 @@ __device__ __forceinline__ uint64_t position_hash(uint32_t my_dword, int side)
     return mix64((((uint64_t)hhi << 32) | hlo) ^ (0x9E3779B97F4A7C15ull * (uint64_t)(side + 2)));
 }
 
+// The evaluation cache is written and read by waves of every XCD: every access goes past the L2s (agent-scope atomics), like
+// the dedupe table's, so that nothing rests on what a kernel boundary does to the eight L2s.
+
 // Evaluation cache, fill side: the wave that consumes a leaf whose probe reserved entry i writes the position, its priors
 // (before any root noise) and its value, then the state word.  Readers accept the entry from the next launch on.
 __device__ __forceinline__ void eval_cache_fill(const Eng &E, int i, uint32_t board_dword /* lane < 12 */, int side, int n,
@@ -565,13 +592,11 @@ __device__ __forceinline__ void eval_cache_fill(const Eng &E, int i, uint32_t bo
     else if (lane == 13) k = (uint32_t)n;
     else if (lane == 14) k = __float_as_uint(value);
     else if (lane == 15) k = 0u;
-    if (lane < 16) E.ec_key[(size_t)i * 16 + lane] = k;
-    if (lane < n) E.ec_prior[(size_t)i * MAXM + lane] = p0;
-    if (lane + 64 < n) E.ec_prior[(size_t)i * MAXM + 64 + lane] = p1;
-    if (lane == 0) {
-        E.ec_state[i] = ((unsigned long long)E.ec_epoch << 32) | E.ec_seq;
-        atomicAdd(&E.ec_stats[1], 1ull);
-    }
+    if (lane < 16) ec_st(&E.ec_key[(size_t)i * 16 + lane], k);
+    if (lane < n) ec_st(reinterpret_cast<uint32_t *>(&E.ec_prior[(size_t)i * MAXM + lane]), __float_as_uint(p0));
+    if (lane + 64 < n) ec_st(reinterpret_cast<uint32_t *>(&E.ec_prior[(size_t)i * MAXM + 64 + lane]), __float_as_uint(p1));
+    // (readers trust the state word from the next launch on: by then every store of this launch has completed)
+    if (lane == 0) ec_st64(&E.ec_state[i], ((unsigned long long)E.ec_epoch << 32) | E.ec_seq);
 }
 
 struct DedupeLook {            // what dedupe_prepare hands to dedupe_finish
@@ -603,28 +628,31 @@ __device__ __forceinline__ DedupeLook dedupe_prepare(const Eng &E, int slot, uin
 // the leaf fills it), or -1 (no luck: evaluated, not kept).  An entry is read only if it was filled in an EARLIER launch -
 // kernel boundaries make it visible, nothing inside a launch has to - and within the last two plies (the epoch): older
 // entries are free to be taken over, so the table needs no clearing and stays as small as two plies of evaluations.
-__device__ __forceinline__ int eval_cache_probe(const Eng &E, uint64_t h, uint32_t my_dword, int side)
+//
+// `first` / `have_first`: the state word of the first entry, loaded by the caller ahead of time (the search kernel sends the
+// look on its way before the move generation: one of the probe's two memory round trips is then hidden).
+__device__ __forceinline__ unsigned eval_cache_pos(const Eng &E, uint64_t h) { return (unsigned)(h >> 24) & (unsigned)E.ec_mask; }
+
+__device__ __forceinline__ int eval_cache_probe(const Eng &E, uint64_t h, uint32_t my_dword, int side,
+                                                unsigned long long first = 0ull, bool have_first = false)
 {
     const int lane = XQ_LANE;
     const unsigned mask = (unsigned)E.ec_mask, epoch = E.ec_epoch, seq = E.ec_seq;
-    unsigned pos = (unsigned)(h >> 24) & mask;
+    unsigned pos = eval_cache_pos(E, h);
     for (int probe = 0; probe < 4; probe++, pos = (pos + 1) & mask) {
-        const unsigned long long raw = E.ec_state[pos];
-        const unsigned long long st = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(raw >> 32)) << 32) |
-                                      __builtin_amdgcn_readfirstlane((uint32_t)raw);
+        const unsigned long long raw = (probe == 0 && have_first) ? first : ec_ld64(&E.ec_state[pos]);
+        const unsigned long long st = uni64(raw);
         const unsigned ep = (unsigned)(st >> 32), filled = (unsigned)st;
         if (epoch - ep > 1u) {                                  // older than the ply before this one (or never used): take it
             unsigned long long old = 0;
             if (lane == 0) old = atomicCAS(&E.ec_state[pos], st, ((unsigned long long)epoch << 32) | 0xffffffffull);
-            old = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(old >> 32)) << 32) |
-                  __builtin_amdgcn_readfirstlane((uint32_t)old);
+            old = uni64(old);
             return old == st ? -(int)pos - 2 : -1;              // (lost the race: most likely to a wave with this very position)
         }
         if (filled >= seq) return -1;                           // reserved or filled in this launch: contents not visible yet
-        const uint32_t theirs = lane < 13 ? E.ec_key[(size_t)pos * 16 + lane] : 0u;
+        const uint32_t theirs = lane < 13 ? ec_ld(&E.ec_key[(size_t)pos * 16 + lane]) : 0u;
         const uint32_t mine = lane < 12 ? my_dword : (uint32_t)(side + 2);
         if (__ballot(lane < 13 && theirs != mine) == 0ull) {
-            if (lane == 0) atomicAdd(&E.ec_stats[0], 1ull);
             return (int)pos;
         }
     }
@@ -646,8 +674,7 @@ __device__ __forceinline__ void dedupe_finish(const Eng &E, int slot, uint32_t m
         if ((unsigned)(ent >> 32) != tag) {                             // left by an earlier round: free
             unsigned long long old = 0;
             if (lane == 0) old = atomicCAS(&E.dd_tab[pos], ent, mine);
-            old = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(old >> 32)) << 32) |
-                  __builtin_amdgcn_readfirstlane((uint32_t)old);
+            old = uni64(old);
             if (old == ent) break;                                      // claimed: lowest slot of its position so far
             ent = old;                                                  // a wave of this round got there first
         }
@@ -708,7 +735,7 @@ __device__ __forceinline__ void record_leaf(const Eng &E, int slot, WaveLds &L, 
         if (lane == 0) E.leaf_ec[slot] = ec;
     }
     // (last: the planes' stores travel while it waits for the table; a leaf the cache answers needs no row at all)
-    if (E.dedupe && ec < 0) dedupe_finish(E, slot, my_dword, side, dedupe_prepare(E, slot, my_dword, side, h));
+    if (E.dedupe && (ec < 0 || E.ec_on == 2)) dedupe_finish(E, slot, my_dword, side, dedupe_prepare(E, slot, my_dword, side, h));
     if (st && lane == 0) st[9] = __builtin_amdgcn_s_memtime();
 }
 
@@ -1026,12 +1053,13 @@ __device__ void search_round_one(const Eng &E, WaveLds &L, int round, int batch_
         if (lane < depth) L.path_node[lane] = (uint16_t)pth;
         double v;
         float p0 = 0.f, p1 = 0.f;
-        if (p_ec >= 0) {
+        if (p_ec >= 0 && E.ec_on == 1) {
             // the evaluation cache holds this position's priors and value (the same bits the network would return)
             const float *pr = E.ec_prior + (size_t)p_ec * MAXM;
-            if (lane < n) p0 = pr[lane];
-            if (lane + 64 < n) p1 = pr[lane + 64];
-            v = (double)__uint_as_float(E.ec_key[(size_t)p_ec * 16 + 14]);
+            if (lane < n) p0 = ec_ldf(pr + lane);
+            if (lane + 64 < n) p1 = ec_ldf(pr + lane + 64);
+            v = (double)__uint_as_float(ec_ld(&E.ec_key[(size_t)p_ec * 16 + 14]));
+            if (lane == 0) E.ec_stats[slot] += 1u;
         } else if (eval_kind == XQ_EVAL_PRIORS) {
             const float *pr = reinterpret_cast<const float *>(ev_a) + (size_t)slot * MAXM;
             if (lane < n) p0 = pr[lane];
@@ -1063,7 +1091,18 @@ __device__ void search_round_one(const Eng &E, WaveLds &L, int round, int batch_
 #pragma unroll
             for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d, 64);
             p0 = e0 / sum; p1 = e1 / sum;
-            if (p_ec <= -2) eval_cache_fill(E, -p_ec - 2, lbw, lside, n, p0, p1, (float)v);
+            if (p_ec <= -2) {
+                eval_cache_fill(E, -p_ec - 2, lbw, lside, n, p0, p1, (float)v);
+                if (lane == 0) E.ec_stats[E.ec_stat_stride + slot] += 1u;
+            } else if (p_ec >= 0) {
+                // verify mode (ec_on == 2): the leaf was evaluated although the cache holds its position - they must agree
+                const float *pr = E.ec_prior + (size_t)p_ec * MAXM;
+                const bool bad = (lane < n && __float_as_uint(ec_ldf(pr + lane)) != __float_as_uint(p0)) ||
+                                 (lane + 64 < n && __float_as_uint(ec_ldf(pr + lane + 64)) != __float_as_uint(p1)) ||
+                                 ec_ld(&E.ec_key[(size_t)p_ec * 16 + 14]) != __float_as_uint((float)v) || ec_ld(&E.ec_key[(size_t)p_ec * 16 + 13]) != (uint32_t)n;
+                const bool any = __ballot(bad) != 0ull;
+                if (lane == 0) { E.ec_stats[slot] += 1u; if (any) E.ec_stats[2 * E.ec_stat_stride + slot] += 1u; }
+            }
         }
         if (E.noise_eps > 0.0 && p_node == root) root_noise(E, g, gs.n_plies, n, p0, p1);
         const bool fits = p_first + n <= E.ncap;
@@ -1190,10 +1229,12 @@ __device__ void search_round_one(const Eng &E, WaveLds &L, int round, int batch_
             const int leaf_side = -st.side;
             uint32_t my_dword = 0;
             uint64_t h = 0;
+            unsigned long long ec_first = 0ull;
             DedupeLook look{ 0u, 0ull };
             auto early = [&](const int8_t *bd) {
                 my_dword = lane < 12 ? pack_dword(bd, lane) : 0u;
                 if (E.dedupe || E.ec_on) h = position_hash(my_dword, leaf_side);
+                if (E.ec_on) ec_first = ec_ld64(&E.ec_state[eval_cache_pos(E, h)]);
                 if (E.dedupe) look = dedupe_prepare(E, slot, my_dword, leaf_side, h);
                 else {
                     if (lane < 12) E.leaf_board[(size_t)slot * 12 + lane] = my_dword;
@@ -1219,10 +1260,10 @@ __device__ void search_round_one(const Eng &E, WaveLds &L, int round, int batch_
                 const uint32_t bdw = lane < 12 ? pack_dword(L.bd, lane) : 0u;
                 int ec = -1;
                 if (E.ec_on) {
-                    ec = eval_cache_probe(E, h, bdw, leaf_side);
+                    ec = eval_cache_probe(E, h, bdw, leaf_side, ec_first, true);
                     if (lane == 0) E.leaf_ec[slot] = ec;
                 }
-                if (E.dedupe && ec < 0) dedupe_finish(E, slot, bdw, leaf_side, look);
+                if (E.dedupe && (ec < 0 || E.ec_on == 2)) dedupe_finish(E, slot, bdw, leaf_side, look);
                 if (STAMP && lane == 0) stp[9] = __builtin_amdgcn_s_memtime();
                 return;
             }
@@ -1316,7 +1357,7 @@ __global__ __launch_bounds__(1024) void k_assign_rows(Eng E, int n_slots, unsign
             const uint32_t v = (i & 1) ? w[i >> 1] >> 16 : w[i >> 1] & 0xffffu;
             if (v != LEAF_NONE) flags |= 1u << i;
         }
-        if (E.ec_on) {
+        if (E.ec_on == 1) {
             // a pending leaf the evaluation cache answers (leaf_ec >= 0) needs no row
             uint32_t cached = 0;
             if (s0 + 16 <= n_slots) {
@@ -2486,6 +2527,8 @@ extern "C" int xq_engine_set_leaf_dedupe(xq_engine *e, int enable)
 extern "C" int xq_engine_set_eval_cache(xq_engine *e, int log2_entries)
 {
     if (!e) return fail(XQ_E_INVALID, "null engine");
+    const bool verify = log2_entries < 0;          // (diagnostic: -log2_entries = the size; hits keep their rows and are compared)
+    if (verify) log2_entries = -log2_entries;
     if (log2_entries == 0) { e->E.ec_on = 0; return 0; }
     if (log2_entries < 10 || log2_entries > 24) return fail(XQ_E_INVALID, "eval cache: 10 <= log2_entries <= 24");
     HIPCHK(hipSetDevice(e->cfg.device));
@@ -2495,26 +2538,32 @@ extern "C" int xq_engine_set_eval_cache(xq_engine *e, int log2_entries)
         int bad = dalloc(e, e->E.ec_state, n);
         bad |= dalloc(e, e->E.ec_key, n * 16); bad |= dalloc(e, e->E.ec_prior, n * MAXM);
         if (!e->E.leaf_ec) bad |= dalloc(e, e->E.leaf_ec, (size_t)e->E.G * 64);
-        if (!e->E.ec_stats) bad |= dalloc(e, e->E.ec_stats, (size_t)2);
+        if (!e->E.ec_stats) bad |= dalloc(e, e->E.ec_stats, (size_t)3 * e->E.G * 64);
         if (bad) return fail(XQ_E_HIP, "hipMalloc failed for the evaluation cache");
         HIPCHK(hipMemsetAsync(e->E.leaf_ec, 0xff, (size_t)e->E.G * 64 * 4, e->stream));
         e->E.ec_mask = (int)(n - 1);
     }
     e->ec_epoch += 2;
-    e->E.ec_on = 1;
+    e->E.ec_on = verify ? 2 : 1;
+    e->E.ec_stat_stride = e->E.G * 64;
     return 0;
 }
 
-// hits / fills since the last reset (diagnostic of the evaluation cache)
-extern "C" int xq_engine_eval_cache_stats(xq_engine *e, uint64_t *hits_fills_host /*[2]*/, int reset)
+// hits / fills / verify-mode mismatches since the last reset (diagnostic of the evaluation cache; counted per slot on the
+// device - a shared counter would be 16,384 atomics on one address per launch - and summed here)
+extern "C" int xq_engine_eval_cache_stats(xq_engine *e, uint64_t *hits_fills_host /*[3]*/, int reset)
 {
     if (!e || !hits_fills_host) return fail(XQ_E_INVALID, "null argument");
-    hits_fills_host[0] = hits_fills_host[1] = 0;
+    hits_fills_host[0] = hits_fills_host[1] = hits_fills_host[2] = 0;
     if (!e->E.ec_stats) return 0;
     HIPCHK(hipSetDevice(e->cfg.device));
-    HIPCHK(hipMemcpyAsync(hits_fills_host, e->E.ec_stats, 16, hipMemcpyDeviceToHost, e->stream));
+    const size_t n = (size_t)3 * e->E.G * 64;
+    std::vector<uint32_t> h(n);
+    HIPCHK(hipMemcpyAsync(h.data(), e->E.ec_stats, n * 4, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
-    if (reset) HIPCHK(hipMemsetAsync(e->E.ec_stats, 0, 16, e->stream));
+    for (int k = 0; k < 3; k++)
+        for (size_t i = 0; i < n / 3; i++) hits_fills_host[k] += h[k * (n / 3) + i];
+    if (reset) HIPCHK(hipMemsetAsync(e->E.ec_stats, 0, n * 4, e->stream));
     return 0;
 }
 

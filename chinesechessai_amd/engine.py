@@ -113,6 +113,8 @@ class TorchNetEvaluator:
         self.leaf_dedupe = bool(leaf_dedupe and self.row_compaction)
         # ... and a position evaluated during the last two plies - by any game - need not be evaluated again
         # (SelfPlayEngine.set_eval_cache; `eval_cache=False` evaluates every leaf the reference would)
+        # (eval_cache="verify": leaves the cache could answer are evaluated all the same and compared with its entry)
+        self.eval_cache_verify = eval_cache == "verify"
         self.eval_cache = bool(eval_cache and self.row_compaction)
         self.row_src = self.n_rows_dev = None
 
@@ -121,7 +123,7 @@ class TorchNetEvaluator:
         engine.set_row_compaction(self.row_compaction)
         if self.row_compaction:
             engine.set_leaf_dedupe(self.leaf_dedupe)
-            engine.set_eval_cache(self.eval_cache)
+            engine.set_eval_cache(self.eval_cache, verify=self.eval_cache_verify)
         self.row_src, self.n_rows_dev = engine.row_map()
         G = engine.n_rows                                       # one row per pending-leaf slot
         if self.channels_last:
@@ -308,7 +310,7 @@ class SelfPlayEngine:
         _lib.check(self.L.xq_engine_set_leaf_dedupe(self.h, 1 if enable else 0))
         self.leaf_dedupe = bool(enable)
 
-    def set_eval_cache(self, enable=True, log2_entries=None):
+    def set_eval_cache(self, enable=True, log2_entries=None, verify=False):
         """Evaluation cache (xq_engine_set_eval_cache): the evaluator's priors and value for a position are kept in HBM for
         two plies; a later pending leaf that is the same position - in any game - takes them from there instead of
         becoming an evaluator row.  What it removes: the reference rebuilds its tree every ply (self_play.py:98), so
@@ -324,14 +326,15 @@ class SelfPlayEngine:
         if log2_entries is None:
             want = 4 * self.rounds * self.n_rows
             log2_entries = min(22, max(12, int(np.ceil(np.log2(max(want, 2))))))
-        _lib.check(self.L.xq_engine_set_eval_cache(self.h, int(log2_entries)))
+        # verify: leaves the cache could answer are evaluated all the same and compared with its entry (eval_cache_stats()[2])
+        _lib.check(self.L.xq_engine_set_eval_cache(self.h, -int(log2_entries) if verify else int(log2_entries)))
         self.eval_cache = True
 
     def eval_cache_stats(self, reset=False):
-        """(hits, fills) of the evaluation cache since the last reset."""
-        out = np.zeros(2, np.uint64)
+        """(hits, fills, mismatches found in verify mode) of the evaluation cache since the last reset."""
+        out = np.zeros(3, np.uint64)
         _lib.check(self.L.xq_engine_eval_cache_stats(self.h, _lib.ptr(out), 1 if reset else 0))
-        return int(out[0]), int(out[1])
+        return int(out[0]), int(out[1]), int(out[2])
 
     def row_map(self):
         """(row_src, row_count) device pointers as ints, or (None, None) without compaction."""

@@ -306,9 +306,12 @@ int  xq_engine_set_leaf_dedupe(xq_engine *e, int enable);
  * xq_value_head_bf16: one fixed fp32 chain per output element whatever the row and the launch).  An entry is used from
  * the launch after the one that filled it; xq_engine_new_games / set_roots / refill_begin age every entry out (new
  * weights must come with one of them).  Works with XQ_EVAL_LOGITS_* output; priors handed in by slot are not cached.
- * xq_engine_eval_cache_stats: hits and fills since the last reset (diagnostic). */
+ * A negative log2_entries switches the cache to VERIFY mode with 2^-log2_entries entries: a leaf the cache could answer
+ * is evaluated all the same and its priors, value and move count are compared with the entry's (a self-check of the
+ * "depends on the position only" promise).  xq_engine_eval_cache_stats: leaves answered (verify mode: compared), entries
+ * filled, and mismatches found in verify mode, since the last reset. */
 int  xq_engine_set_eval_cache(xq_engine *e, int log2_entries);
-int  xq_engine_eval_cache_stats(xq_engine *e, uint64_t *hits_fills_host /* [2] */, int reset);
+int  xq_engine_eval_cache_stats(xq_engine *e, uint64_t *hits_fills_mismatches_host /* [3] */, int reset);
 
 /* ---- refill: `total` games through the engine's G concurrent slots, a finished game's slot being restarted
  * on the next unplayed game at once — what the reference's pool does by construction (imap_unordered hands a

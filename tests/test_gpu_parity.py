@@ -1708,9 +1708,10 @@ def test_root_eval_carry_is_result_identical(L):
     # the bf16 network
     torch.manual_seed(1)
     net = ChessNet(num_blocks=2).eval().cuda()
-    # (leaf_dedupe=False: the row accounting below is the compaction's; tests/test_gpu_round3.py covers the dedupe)
-    a, ra = play(lambda: TorchNetEvaluator(net, leaf_dedupe=False), 96, 24, False, max_moves=14)
-    b, rb = play(lambda: TorchNetEvaluator(net, leaf_dedupe=False), 96, 24, True, max_moves=14)
+    # (leaf_dedupe=False, eval_cache=False: the row accounting below is the compaction's; tests/test_gpu_round3.py covers the
+    # dedupe, tests/test_gpu_round5.py the evaluation cache - which would answer the roots the no-carry path evaluates again)
+    a, ra = play(lambda: TorchNetEvaluator(net, leaf_dedupe=False, eval_cache=False), 96, 24, False, max_moves=14)
+    b, rb = play(lambda: TorchNetEvaluator(net, leaf_dedupe=False, eval_cache=False), 96, 24, True, max_moves=14)
     assert np.array_equal(a.chosen, b.chosen) and np.array_equal(a.s_counts, b.s_counts)
     assert np.array_equal(a.s_z.view(np.int64), b.s_z.view(np.int64)) and int(b.error.sum()) == 0
     # the hand-written evaluator runs with row compaction: every round is launched, a carried root has no row in round 0

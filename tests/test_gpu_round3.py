@@ -46,7 +46,7 @@ def test_row_compaction_is_result_identical_and_skips_dead_rows(L):
     seeds = np.arange(G, dtype=np.uint32)
 
     def run(compact, carry):
-        ev = TorchNetEvaluator(net, leaf_dedupe=False)      # (row accounting of the compaction alone; the dedupe has its own test)
+        ev = TorchNetEvaluator(net, leaf_dedupe=False, eval_cache=False)      # (row accounting of the compaction alone; the dedupe has its own test)
         assert ev.row_compaction                    # the hand-written single-launch path asks for it
         ev.row_compaction = compact
         eng = SelfPlayEngine(G, sims=S, planes_format=ev.planes_format, max_moves=P)
@@ -69,7 +69,7 @@ def test_row_compaction_is_result_identical_and_skips_dead_rows(L):
             assert (per[1:, 0] == (0 if carry else G)).all()
 
     # round by round: the carried-over roots of ply 1 have no row in round 0, every slot has one in round 1
-    ev = TorchNetEvaluator(net, leaf_dedupe=False)
+    ev = TorchNetEvaluator(net, leaf_dedupe=False, eval_cache=False)
     eng = SelfPlayEngine(G, sims=S, planes_format=ev.planes_format, max_moves=P)
     eng.set_root_eval_carry(True)
     ev.bind(eng)
@@ -111,7 +111,7 @@ def test_c3_full_size_root_eval_carry_is_identical(L):
     seeds = np.arange(G, dtype=np.uint32)
 
     def run(carry):
-        ev = TorchNetEvaluator(net, leaf_dedupe=False)
+        ev = TorchNetEvaluator(net, leaf_dedupe=False, eval_cache=False)
         eng = SelfPlayEngine(G, sims=S, planes_format=ev.planes_format, max_moves=P)
         eng.set_root_eval_carry(carry)
         b = eng.play(ev, seeds)
@@ -155,7 +155,7 @@ def test_leaf_dedupe_is_result_identical_and_groups_exactly(L):
     keys = ("chosen", "s_counts", "s_moves", "s_n", "winner", "reason", "n_plies", "n_samples", "error")
 
     def run(net, G, S, P, dedupe, carry=None, vloss=False, seeds=seeds):
-        ev = TorchNetEvaluator(net, leaf_dedupe=dedupe)
+        ev = TorchNetEvaluator(net, leaf_dedupe=dedupe, eval_cache=False)
         assert ev.row_compaction and ev.leaf_dedupe == dedupe
         eng = SelfPlayEngine(G, sims=S, planes_format=ev.planes_format, max_moves=P)
         if vloss:
@@ -187,7 +187,7 @@ def test_leaf_dedupe_is_result_identical_and_groups_exactly(L):
     # (2) the grouping, round by round: same planes <=> same row, rows in order of the lowest slot - 8 plies of the small
     # batch, then 7 plies of 16,384 games (the search kernel's waves of all 256 CUs meet in the table)
     def grouping(net, G, S, plies):
-        ev = TorchNetEvaluator(net)
+        ev = TorchNetEvaluator(net, eval_cache=False)
         eng = SelfPlayEngine(G, sims=S, planes_format=ev.planes_format, max_moves=plies + 1)
         ev.bind(eng)
         eng.new_games(np.arange(G, dtype=np.uint32))

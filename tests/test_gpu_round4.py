@@ -73,7 +73,7 @@ def test_refill_with_the_real_network_equals_lock_step_play(L):
     seeds = (np.arange(T, dtype=np.uint32) * 7 + 3).astype(np.uint32)
 
     # the plain path: lock-step, no carry-over, no dedupe
-    ev = TorchNetEvaluator(net, leaf_dedupe=False)
+    ev = TorchNetEvaluator(net, leaf_dedupe=False, eval_cache=False)
     eng = SelfPlayEngine(T, sims=S, planes_format=ev.planes_format)
     eng.set_root_eval_carry(False)
     eng.play(ev, seeds, read=False)
@@ -89,7 +89,7 @@ def test_refill_with_the_real_network_equals_lock_step_play(L):
 
     block = 70 * xd.RECORD_BYTES
     for dedupe in (True, False):
-        ev = TorchNetEvaluator(net, leaf_dedupe=dedupe)
+        ev = TorchNetEvaluator(net, leaf_dedupe=dedupe, eval_cache=False)
         eng = SelfPlayEngine(G, sims=S, planes_format=ev.planes_format)
         buf = torch.full(((T + 2) * block,), 0xA5, dtype=torch.uint8, device="cuda")
         seen = []

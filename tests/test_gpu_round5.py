@@ -130,7 +130,7 @@ def test_refill_with_dedupe_and_carry_at_a_contended_size(L):
     rec_all = buf[block:-block].view(T, block)
     rec = np.frombuffer(rec_all[torch.as_tensor(sample, device="cuda")].cpu().numpy().tobytes(),
                         dtype=xd.RECORD_DTYPE).reshape(len(sample), 70)
-    evp = TorchNetEvaluator(net, leaf_dedupe=False)
+    evp = TorchNetEvaluator(net, leaf_dedupe=False, eval_cache=False)
     engp = SelfPlayEngine(len(sample), sims=S, planes_format=evp.planes_format)
     engp.set_root_eval_carry(False)
     engp.play(evp, seeds[sample], read=False)
@@ -218,10 +218,10 @@ def test_eval_cache_is_result_identical_and_answers_for_peaked_priors(L):
         return xd.records_to_numpy(t).reshape(G, 70), out, int(rows.astype(np.int64).sum()), stats
 
     ref, ref_out, rows_plain, st0 = run(net, False, False, False)
-    assert st0 == (0, 0) and int(ref_out["error"].sum()) == 0
+    assert st0 == (0, 0, 0) and int(ref_out["error"].sum()) == 0
     assert (ref_out["n_plies"] < 70).sum() >= G // 20                                  # the network ends games early, too
     for dedupe, cache, carry in ((False, True, False), (True, True, True)):
-        rec, out, rows, (hits, fills) = run(net, dedupe, cache, carry)
+        rec, out, rows, (hits, fills, _) = run(net, dedupe, cache, carry)
         for k in ("winner", "reason", "reason_side", "reason_count", "n_plies", "n_samples", "error"):
             assert np.array_equal(out[k], ref_out[k]), (k, dedupe, cache, carry)
         for g in range(G):
@@ -247,3 +247,32 @@ def test_eval_cache_is_result_identical_and_answers_for_peaked_priors(L):
     eng.close()
     assert np.array_equal(b2.s_counts, b2_fresh.s_counts) and np.array_equal(b2.chosen, b2_fresh.chosen)
     assert not np.array_equal(a1.s_counts, b2.s_counts)
+
+
+def test_eval_cache_verify_mode_at_the_bench_size(L):
+    """The evaluation cache checks itself: in verify mode a leaf the cache could answer is evaluated all the same and its
+    priors, value and move count are compared with the entry's, bit for bit.  BASELINE C3's size (16,384 games x S = 50 x
+    6-block bf16, 8 plies, dedupe and carry-over on and off): about 95,000 / 209,000 leaves compared, NO mismatch, and
+    exactly one fill per reserved entry.  (Round 5 found a real bug this way: a sign extension in the 64-bit readfirstlane
+    idiom let every wave that lost the reservation race believe it had won - 30 to 80 mismatches per run.)"""
+    import torch
+    from chinesechessai_amd.engine import SelfPlayEngine, TorchNetEvaluator
+    from chinesechessai_amd.neural_network import ChessNet
+    torch.manual_seed(0)
+    net = ChessNet(num_blocks=6).eval().cuda()
+    G, P = 16384, 8
+    seeds = np.arange(G, dtype=np.uint32)
+    for dedupe, carry in ((True, True), (False, False)):
+        ev = TorchNetEvaluator(net, leaf_dedupe=dedupe, eval_cache="verify")
+        eng = SelfPlayEngine(G, sims=50, planes_format=ev.planes_format, max_moves=P)
+        if not carry:
+            eng.set_root_eval_carry(False)
+        b = eng.play(ev, seeds)
+        compared, fills, bad = eng.eval_cache_stats()
+        eng.close()
+        assert int(b.error.sum()) == 0
+        assert bad == 0, (dedupe, carry, compared, fills, bad)
+        assert compared > 50000 and fills > 50000, (compared, fills)
+        if not carry:
+            # every root of plies 1.. was a leaf of the ply before: the cache knows it
+            assert compared >= G * (P - 1), compared
