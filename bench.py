@@ -492,6 +492,7 @@ def run_rank(args):
     clk = clock_buf.cpu().numpy()
     trunk_clock_ghz = float(clk[0]) / float(clk[1]) * 0.1 if clk[1] > 0 else None
     prof = eng.profile_read()
+    ec_cache_was_on = bool(eng.eval_cache)
     ec_hits_timed = eng.eval_cache_stats(reset=True)[0] if eng.eval_cache else 0
     carry_on = eng._carry_on
     rows_hist, n_rounds = eng.row_history(reset=True) if eng.row_compaction else (None, 0)
@@ -533,14 +534,15 @@ def run_rank(args):
         if ev.eval_cache:
             # the evaluation cache (position -> priors + value, two plies): random-init priors are 0.35 % apart, a search
             # never descends twice into the same child, nothing below the played move is expanded - the cache can answer next
-            # to nothing in the headline workload and costs its probe.  What it is for is a TRAINED network, whose search
-            # follows lines: the same architecture with the policy head's weights and bias scaled by 256 (seeded random-init
+            # to nothing in the headline workload, notices that after its first step and suspends itself (its probe costs the
+            # tree kernel ~10 %: value_eval_cache_forced_on).  What it is for is a TRAINED network, whose search follows
+            # lines: the same architecture with the policy head's weights and bias scaled by 256 (seeded random-init
             # otherwise: the top move then holds ~0.9 of the prior mass), with the cache and without
             import copy
-            ev_nc = make_ev(args.policy_columns, ev.leaf_dedupe, eval_cache=False)
-            step(eng, ev_nc, 10_000_000)
-            aux["value_no_eval_cache"] = timed_steps(ev_nc, 10_100_000)
-            del ev_nc
+            ev_on = make_ev(args.policy_columns, ev.leaf_dedupe, eval_cache="on")
+            step(eng, ev_on, 10_000_000)
+            aux["value_eval_cache_forced_on"] = timed_steps(ev_on, 10_100_000)
+            del ev_on
             net_pk = copy.deepcopy(net)
             with torch.no_grad():
                 net_pk.policy_fc.weight.mul_(256.0)
@@ -656,11 +658,14 @@ def run_rank(args):
                           "position share one network row - every game starts from the same position with the same weights, so "
                           "the first plies of a step repeat across games: %d rows evaluated in this run of %d forwards; value_no_dedupe is "
                           "the figure with one row per pending leaf)" % (int(rows_fw.sum()), n_fw))
-        if eng.eval_cache:
-            extras.append("; evaluation cache ON (result-identical, tested: a position's priors and value are kept for two plies and "
-                          "answer for any later leaf that is the same position; %d leaves answered in this run - random-init priors "
-                          "make the search revisit next to nothing; value_no_eval_cache is the figure without it, "
-                          "value_peaked_priors / _no_reuse show what it is for)" % ec_hits_timed)
+        if ev.eval_cache:
+            extras.append("; evaluation cache (result-identical, tested: a position's priors and value are kept for two plies and answer "
+                          "for any later leaf that is the same position) %s; value_eval_cache_forced_on is the figure with it "
+                          "always on, value_peaked_priors / _no_reuse show what it is for" % (
+                              "ON: %d leaves answered in this run" % ec_hits_timed if ec_cache_was_on else
+                              "adaptive: it answered %s in its last step (random-init priors make the search revisit next to "
+                              "nothing; an answer saves a row, the probe costs the tree kernel ~10 %%) and suspended itself for the timed steps" % (
+                                  "%d, against %d rows evaluated," % (ev.eval_cache_last[0], ev.eval_cache_last[2]) if ev.eval_cache_last else "none")))
         if args.tree_reuse:
             extras.append(", tree reuse (extension)")
         if args.virtual_loss:

@@ -2557,13 +2557,14 @@ extern "C" int xq_engine_eval_cache_stats(xq_engine *e, uint64_t *hits_fills_hos
     hits_fills_host[0] = hits_fills_host[1] = hits_fills_host[2] = 0;
     if (!e->E.ec_stats) return 0;
     HIPCHK(hipSetDevice(e->cfg.device));
-    const size_t n = (size_t)3 * e->E.G * 64;
-    std::vector<uint32_t> h(n);
-    HIPCHK(hipMemcpyAsync(h.data(), e->E.ec_stats, n * 4, hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipStreamSynchronize(e->stream));
-    for (int k = 0; k < 3; k++)
-        for (size_t i = 0; i < n / 3; i++) hits_fills_host[k] += h[k * (n / 3) + i];
-    if (reset) HIPCHK(hipMemsetAsync(e->E.ec_stats, 0, n * 4, e->stream));
+    const size_t stride = (size_t)e->E.G * 64, slots = (size_t)e->E.G * (size_t)e->E.leaf_slots;
+    std::vector<uint32_t> h(slots);
+    for (int k = 0; k < 3; k++) {
+        HIPCHK(hipMemcpyAsync(h.data(), e->E.ec_stats + k * stride, slots * 4, hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+        for (size_t i = 0; i < slots; i++) hits_fills_host[k] += h[i];
+        if (reset) HIPCHK(hipMemsetAsync(e->E.ec_stats + k * stride, 0, slots * 4, e->stream));
+    }
     return 0;
 }
 

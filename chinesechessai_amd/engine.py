@@ -113,9 +113,19 @@ class TorchNetEvaluator:
         self.leaf_dedupe = bool(leaf_dedupe and self.row_compaction)
         # ... and a position evaluated during the last two plies - by any game - need not be evaluated again
         # (SelfPlayEngine.set_eval_cache; `eval_cache=False` evaluates every leaf the reference would)
-        # (eval_cache="verify": leaves the cache could answer are evaluated all the same and compared with its entry)
+        # eval_cache: True = on, and it watches itself: its probe costs the tree kernel ~10 % (0.6-1 % of a step with the
+        # 6-block network) and an answered leaf saves one network row - but with random-init weights the answers (2 % of
+        # the rows at 16,384 games) all fall into the first plies, whose launches the leaf dedupe has already emptied: the
+        # step gets 0.6-1 % SLOWER (measured).  So a whole play() in which it answered fewer leaves than 5 % of the rows
+        # that were evaluated suspends it for the next 15 plays with this evaluator, then it tries again (a trained
+        # network's line-following search: 40-60 %).  "on" = always on; False = off; "verify" = leaves the cache could
+        # answer are evaluated all the same and compared with its entry
         self.eval_cache_verify = eval_cache == "verify"
         self.eval_cache = bool(eval_cache and self.row_compaction)
+        self.eval_cache_adaptive = eval_cache is True
+        self.eval_cache_suspended = 0            # plays left without the cache
+        self.eval_cache_last = None              # (hits, fills, rows evaluated) of the last play that used it
+        self._rounds_at_bind = 0
         self.row_src = self.n_rows_dev = None
 
     def bind(self, engine):
@@ -123,7 +133,11 @@ class TorchNetEvaluator:
         engine.set_row_compaction(self.row_compaction)
         if self.row_compaction:
             engine.set_leaf_dedupe(self.leaf_dedupe)
-            engine.set_eval_cache(self.eval_cache, verify=self.eval_cache_verify)
+            use = self.eval_cache and self.eval_cache_suspended == 0
+            engine.set_eval_cache(use, verify=self.eval_cache_verify)
+            if use:
+                engine.eval_cache_stats(reset=True)
+                self._rounds_at_bind = engine.row_history(cap=0)[1]
         self.row_src, self.n_rows_dev = engine.row_map()
         G = engine.n_rows                                       # one row per pending-leaf slot
         if self.channels_last:
@@ -140,6 +154,21 @@ class TorchNetEvaluator:
 
     def planes_ptr(self):
         return self.storage.data_ptr()
+
+    def after_play(self, engine):
+        """called by SelfPlayEngine.play / play_refill when the games are over: the evaluation cache's self-assessment"""
+        if not self.eval_cache:
+            return
+        if engine.eval_cache:
+            hits, fills, _ = engine.eval_cache_stats()
+            n_now = engine.row_history(cap=0)[1]
+            played = n_now - self._rounds_at_bind if n_now >= self._rounds_at_bind else n_now     # (the caller may have reset the count)
+            rows = int(engine.row_history(cap=max(played, 1))[0].astype(np.int64).sum()) if played > 0 else 0
+            self.eval_cache_last = (hits, fills, rows)
+            if self.eval_cache_adaptive and hits < 0.05 * (rows + hits):
+                self.eval_cache_suspended = 15
+        elif self.eval_cache_suspended > 0:
+            self.eval_cache_suspended -= 1
 
     def evaluate(self, engine):
         G = engine.n_rows
@@ -500,6 +529,9 @@ class SelfPlayEngine:
             if check_every and ply % check_every == check_every - 1 and self.active_games() == 0:
                 break
         _lib.check(self.L.xq_engine_finalize(self.h))
+        for ev in (evaluator, opponent_evaluator):
+            if ev is not None and hasattr(ev, "after_play"):
+                ev.after_play(self)
         return self.read_results() if read else None
 
     def play_refill(self, evaluator, seeds, records_ptr, check_every=4, max_plies=None, on_ply=None):
@@ -530,6 +562,8 @@ class SelfPlayEngine:
                 break
         else:
             raise _lib.XqError("play_refill: games still active after %d plies" % cap)
+        if hasattr(evaluator, "after_play"):
+            evaluator.after_play(self)
         out = {k: np.zeros(total, np.int32) for k in ("winner", "reason", "reason_side", "reason_count", "n_plies",
                                                       "n_samples", "error")}
         _lib.check(self.L.xq_engine_refill_read_games(self.h, *[_lib.ptr(out[k]) for k in (

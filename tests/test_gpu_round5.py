@@ -276,3 +276,36 @@ def test_eval_cache_verify_mode_at_the_bench_size(L):
         if not carry:
             # every root of plies 1.. was a leaf of the ply before: the cache knows it
             assert compared >= G * (P - 1), compared
+
+
+def test_eval_cache_suspends_itself_when_it_answers_nothing(L):
+    """The default (`eval_cache=True`) watches itself: with random-init weights a search revisits next to nothing, the
+    cache answers < 2 % of the leaves it looks up, and after one play it steps aside for the next 15 (its probe is not
+    free); with the mate-line network it stays.  `eval_cache="on"` never steps aside.  Results never change."""
+    import torch
+    from chinesechessai_amd.engine import SelfPlayEngine, TorchNetEvaluator
+    from chinesechessai_amd.neural_network import ChessNet
+    torch.manual_seed(3)
+    net = ChessNet(num_blocks=2).eval().cuda()
+    G = 2048                                         # (whole games: the opening's transpositions are a small share then)
+    seeds = np.arange(G, dtype=np.uint32)
+    ev = TorchNetEvaluator(net)
+    eng = SelfPlayEngine(G, sims=50, planes_format=ev.planes_format)
+    a = eng.play(ev, seeds)
+    hits, fills, rows = ev.eval_cache_last
+    assert eng.eval_cache and ev.eval_cache_suspended == 15 and hits < 0.05 * (rows + hits), ev.eval_cache_last
+    b = eng.play(ev, seeds)
+    assert not eng.eval_cache and ev.eval_cache_suspended == 14
+    assert np.array_equal(a.chosen, b.chosen) and np.array_equal(a.s_counts, b.s_counts)
+    ev_on = TorchNetEvaluator(net, eval_cache="on")
+    eng.play(ev_on, seeds)
+    eng.play(ev_on, seeds)
+    assert eng.eval_cache and ev_on.eval_cache_suspended == 0
+    eng.close()
+    seeds = np.arange(256, dtype=np.uint32)
+    ev = TorchNetEvaluator(_mate_line_net(2, 11))
+    eng = SelfPlayEngine(256, sims=50, planes_format=ev.planes_format, max_moves=12)
+    eng.play(ev, seeds)
+    eng.play(ev, seeds)
+    assert eng.eval_cache and ev.eval_cache_suspended == 0 and ev.eval_cache_last[0] > 0.1 * ev.eval_cache_last[2]
+    eng.close()
