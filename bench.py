@@ -65,6 +65,13 @@ def tree_bytes_per_descent(b=33.3, lvl=0.86):
     return 64 + 16 * b * lvl + 2 * b + 48 + 2880 + (2 * b + 2) + 2 * b + 22 * b + 24 * (lvl + 1)
 
 
+def lib_sha16():
+    """sha256 (16 hex digits) of the HIP library this process runs: what a PMC summary names as the build it profiled"""
+    import hashlib
+    path = os.path.join(ROOT, "chinesechessai_amd", "csrc", "libxq_hip.so")
+    return hashlib.sha256(open(path, "rb").read()).hexdigest()[:16] if os.path.exists(path) else None
+
+
 def pmc_traffic(kernel, G, S, blocks, fetch_factor=1.0):
     """(HBM bytes per launch of `kernel`, where that number comes from).  The PMC counters cannot be read
     from inside this process: the bytes come from the newest committed rocprofv3 pass over this same
@@ -74,15 +81,16 @@ def pmc_traffic(kernel, G, S, blocks, fetch_factor=1.0):
     correction, MI355X_MICROARCH.md); (None, None) for configs that were not profiled."""
     if not (G == 16384 and S == 50 and blocks == 6):
         return None, None
-    for name in ("r04_pmc_kernels.json", "r03_pmc_kernels.json", "r02c_pmc_kernels.json", "r02b_pmc_kernels.json", "r02_pmc_kernels.json", "r01g_pmc_kernels.json", "r01f_pmc_kernels.json", "r01d_pmc_kernels.json"):
+    for name in ("r05_pmc_kernels.json", "r05a_pmc_kernels.json", "r04_pmc_kernels.json", "r03_pmc_kernels.json", "r02c_pmc_kernels.json", "r02b_pmc_kernels.json", "r02_pmc_kernels.json", "r01g_pmc_kernels.json", "r01f_pmc_kernels.json", "r01d_pmc_kernels.json"):
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
             doc = json.load(open(path))
             k = doc["kernels"].get(kernel)
             if k and "FETCH_SIZE_KB_mean_per_launch" in k and "WRITE_SIZE_KB_mean_per_launch" in k:
                 byt = (fetch_factor * k["FETCH_SIZE_KB_mean_per_launch"] + k["WRITE_SIZE_KB_mean_per_launch"]) * 1024.0
-                return byt, "profiles/%s (committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload%s; not measured in this run)" % (
-                    name, ", " + doc["note"] if doc.get("note") else "")
+                return byt, "profiles/%s (committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload%s; build of those passes: %s; not measured in this run)" % (
+                    name, ", " + doc["note"] if doc.get("note") else "",
+                    "libxq_hip.so sha16 " + doc["build_libxq_hip_sha16"] if doc.get("build_libxq_hip_sha16") else "not recorded")
     return None, None
 
 
@@ -713,6 +721,7 @@ def run_rank(args):
                                             "logit gather, edge init, backup%s) + %d launches of round 0 under the carry-over (64 B per game)" % (
                                                 n_search - n_light, bpd, ", dedupe words + table entry" if eng.leaf_dedupe else "", n_light)},
             "traffic_over_algorithmic": traffic_ratio,
+            "build_libxq_hip_sha16": lib_sha16(),
             "time_share": {"net_forward_ms": fw_ms, "k_search_round_ms": prof["search_ms"],
                            "k_play_move_ms": prof["play_ms"], "wall_ms": dt * 1e3},
             "games": {"mean_plies": float(outcomes["n_plies"].mean()),

@@ -157,6 +157,8 @@ _SIGNATURES = {
     "xq_engine_play_move": (C.c_int, [C.c_void_p]),
     "xq_engine_finalize": (C.c_int, [C.c_void_p]),
     "xq_engine_active_games": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "xq_engine_active_games_post": (C.c_int, [C.c_void_p]),
+    "xq_engine_active_games_poll": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "xq_engine_priors_ptr": (C.c_void_p, [C.c_void_p]),
     "xq_engine_values_ptr": (C.c_void_p, [C.c_void_p]),
     "xq_engine_rounds_per_move": (C.c_int, [C.c_void_p]),

@@ -2017,6 +2017,9 @@ struct xq_engine {
     double *pow_table_dev = nullptr;
     int pow_cap = 0;
     int *active_dev = nullptr;
+    int32_t *active_host = nullptr;      // pinned: results of xq_engine_active_games_post
+    hipEvent_t active_ev = nullptr;
+    unsigned active_posted = 0;
     int8_t *stage_boards = nullptr;      // [G][90] staging for set_roots / read_leaves
     int32_t *stage_state = nullptr;      // [G][XQ_STATE_WORDS]
     uint16_t *stage_rmoves = nullptr;    // [G][128] staging for read_root_visits / read_root_priors
@@ -2118,6 +2121,8 @@ extern "C" void xq_engine_destroy(xq_engine *e)
     (void)hipSetDevice(e->cfg.device);
     (void)hipDeviceSynchronize();
     for (void *p : e->allocs) (void)hipFree(p);
+    if (e->active_host) (void)hipHostFree(e->active_host);
+    if (e->active_ev) (void)hipEventDestroy(e->active_ev);
     for (auto &pr : e->ev_search) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     for (auto &pr : e->ev_play) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     delete e;
@@ -2210,6 +2215,7 @@ extern "C" int xq_engine_new_games(xq_engine *e, const uint32_t *seeds)
     HIPCHK(hipStreamSynchronize(e->stream));          // u is a local: copy must finish
     if (e->E.eval_carry) HIPCHK(hipMemsetAsync(e->E.roots_not_ready, 0, 4, e->stream));
     e->ec_epoch += 2;                                                    // new games, possibly new weights: nothing cached survives
+    e->active_posted = 0;                                                // (a count posted for the last games says nothing about these)
     hipLaunchKernelGGL(k_new_games, dim3(e->E.G), dim3(64), 0, e->stream, e->E);
     HIPCHK(hipGetLastError());
     return 0;
@@ -2377,6 +2383,7 @@ extern "C" int xq_engine_set_roots(xq_engine *e, const int8_t *boards, const int
     HIPCHK(hipStreamSynchronize(e->stream));
     if (e->E.eval_carry) HIPCHK(hipMemsetAsync(e->E.roots_not_ready, 0, 4, e->stream));     // k_set_roots counts them
     e->ec_epoch += 2;
+    e->active_posted = 0;
     hipLaunchKernelGGL(k_set_roots, dim3(e->E.G), dim3(64), 0, e->stream, e->E, e->stage_boards, e->stage_state);
     HIPCHK(hipGetLastError());
     return 0;
@@ -2718,7 +2725,7 @@ extern "C" int xq_engine_refill_begin(xq_engine *e, const uint32_t *seeds, int t
     HIPCHK(hipStreamSynchronize(e->stream));          // locals: the copies must finish
     if (e->E.eval_carry) HIPCHK(hipMemsetAsync(e->E.roots_not_ready, 0, 4, e->stream));
     e->ec_epoch += 2;                                                    // new games, possibly new weights: nothing cached survives
-    e->ec_epoch += 2;
+    e->active_posted = 0;                                                // (a count posted for the last games says nothing about these)
     hipLaunchKernelGGL(k_new_games, dim3(e->E.G), dim3(64), 0, e->stream, e->E);
     HIPCHK(hipGetLastError());
     return 0;
@@ -2781,6 +2788,43 @@ extern "C" int xq_engine_active_games(xq_engine *e, int32_t *n)
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(n, e->active_dev, 4, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
+    return 0;
+}
+
+// The same count without stopping the host: _post enqueues the count and its copy into pinned host memory behind
+// everything enqueued so far; _poll says whether the newest posted count has arrived (1) or not yet (0) and hands it out.
+// A driver loop that posts every few plies and polls before it posts learns "all games over" a few plies late - plies of
+// finished games cost next to nothing - and never drains the stream (the blocking form leaves the GPU idle until the
+// host has enqueued the next ply again: ~0.3 % of a lock-step epoch).
+extern "C" int xq_engine_active_games_post(xq_engine *e)
+{
+    if (!e) return fail(XQ_E_INVALID, "null engine");
+    HIPCHK(hipSetDevice(e->cfg.device));
+    if (!e->active_host) {
+        HIPCHK(hipHostMalloc((void **)&e->active_host, 2 * sizeof(int32_t)));
+        HIPCHK(hipEventCreateWithFlags(&e->active_ev, hipEventDisableTiming));
+    }
+    // two dwords in turn, so that a count being written is never the one being read
+    const int slot = e->active_posted & 1;
+    HIPCHK(hipMemsetAsync(e->active_dev, 0, 4, e->stream));
+    hipLaunchKernelGGL(k_count_active, dim3((e->E.G + 255) / 256), dim3(256), 0, e->stream, e->E.gs, e->E.G, e->active_dev);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(e->active_host + slot, e->active_dev, 4, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipEventRecord(e->active_ev, e->stream));
+    e->active_posted++;
+    return 0;
+}
+
+extern "C" int xq_engine_active_games_poll(xq_engine *e, int32_t *n, int32_t *ready)
+{
+    if (!e || !n || !ready) return fail(XQ_E_INVALID, "null argument");
+    *ready = 0;
+    if (!e->active_host || e->active_posted == 0) return 0;
+    const hipError_t q = hipEventQuery(e->active_ev);
+    if (q == hipErrorNotReady) return 0;
+    if (q != hipSuccess) return fail(XQ_E_HIP, "hipEventQuery failed");
+    *n = e->active_host[(e->active_posted - 1) & 1];
+    *ready = 1;
     return 0;
 }
 

@@ -209,6 +209,11 @@ int  xq_engine_finalize(xq_engine *e);
 
 /* number of games still running (synchronises the stream) */
 int  xq_engine_active_games(xq_engine *e, int32_t *n_active_host);
+/* The same count without blocking (the loop of self_play.py:203 polls `done` every ply; a device-side engine should not stop
+ * for it): _post enqueues the count behind everything enqueued so far, _poll sets *ready to 1 and *n_active_host to the
+ * newest posted count once it has arrived, else *ready = 0. */
+int  xq_engine_active_games_post(xq_engine *e);
+int  xq_engine_active_games_poll(xq_engine *e, int32_t *n_active_host, int32_t *ready);
 
 /* device pointers of engine-owned buffers (valid for the engine's lifetime) */
 void *xq_engine_priors_ptr(xq_engine *e);      /* float32 [G][128]  */

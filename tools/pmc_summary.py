@@ -47,7 +47,11 @@ def main():
             unit = "_KB" if counter in ("FETCH_SIZE", "WRITE_SIZE") else ""
             e["%s%s_mean_per_launch" % (counter, unit)] = total / max(len(ids), 1)
             e["launches_%s" % counter] = len(ids)
-    json.dump({"note": note, "kernels": kernels}, open(out, "w"), indent=1)
+    # which build the passes profiled: sha256 of the in-tree HIP library (16 hex digits), as bench.py reports for the one it runs
+    import hashlib
+    lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "chinesechessai_amd", "csrc", "libxq_hip.so")
+    build = hashlib.sha256(open(lib, "rb").read()).hexdigest()[:16] if os.path.exists(lib) else None
+    json.dump({"note": note, "build_libxq_hip_sha16": build, "kernels": kernels}, open(out, "w"), indent=1)
     for k, v in sorted(kernels.items()):
         print(k, v)
 

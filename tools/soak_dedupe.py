@@ -28,7 +28,7 @@ while time.time() - t0 < budget:
         G = min(G, 2048)
     S = int(rng.choice([16, 24, 50]))
     plies = int(rng.integers(3, 12))
-    ev = TorchNetEvaluator(net)
+    ev = TorchNetEvaluator(net, eval_cache=False)      # (row accounting of the dedupe alone)
     eng = SelfPlayEngine(G, sims=S, planes_format=ev.planes_format, max_moves=plies + 1)
     if vl:
         eng.set_virtual_loss(True)

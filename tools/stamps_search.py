@@ -12,7 +12,7 @@ plies = int(sys.argv[1]) if len(sys.argv) > 1 else 6
 torch.manual_seed(0)
 net = ChessNet(num_blocks=6).eval().cuda()
 G = 16384
-ev = TorchNetEvaluator(net)
+ev = TorchNetEvaluator(net, eval_cache=False)
 eng = SelfPlayEngine(G, sims=50, planes_format=ev.planes_format)
 eng._auto_carry(ev, None)
 eng._bind(ev)
