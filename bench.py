@@ -217,7 +217,7 @@ def main():
     ap.add_argument("--virtual-loss", action="store_true", help="extension: up to 8 distinct leaves per game and round (8x the network rows)")
     ap.add_argument("--fused-tower", type=int, default=1, help="1 = whole trunk in one launch (k_tower), 0 = one launch per convolution")
     ap.add_argument("--tower-variant", type=int, default=-1, help="diagnostic: trunk kernel build (-1 = library default: 60 = k_tower1wa from 2,048 boards up, 36 below; 36 / 39 = k_tower16b with 2 / 4 boards per workgroup; 0 = 32x32x16)")
-    ap.add_argument("--fc-variant", type=int, default=-1, help="diagnostic: policy FC kernel (-1 = library default = 0: k_policy_fc; 1 = k_policy_fc1w, one wave per SIMD with a generated asm body)")
+    ap.add_argument("--fc-variant", type=int, default=-1, help="diagnostic: policy FC kernel (-1 = library default = 1: k_policy_fc1w, one wave per SIMD with a generated asm body; 0 = k_policy_fc, 8 waves, HIP)")
     ap.add_argument("--conv-variant", type=int, default=0, help="diagnostic: 1 = 2 boards/WG, 2 = 4 boards/WG (0 = library default)")
     args = ap.parse_args()
     if args.gpus < 1:

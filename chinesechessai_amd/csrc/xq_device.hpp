@@ -1,10 +1,10 @@
 // xq_device.hpp — wave-cooperative Xiangqi rules for gfx950 (CDNA4, wave64).
 //
-// One 64-lane wavefront owns one game.  The 10x9 board lives as 90 signed bytes in LDS for the
-// duration of a kernel (nibble-packed, 48 B, in HBM); occupancy is held as wave-uniform 90-bit
-// bitboards produced by __ballot (row-major and column-major), so that ray scans, "pieces
-// between" counts and the legality filter are a handful of bit operations per lane instead of
-// board walks.  Nothing here is a translation of the reference's Python: the behaviour
+// One 64-lane wavefront owns one game.  The 10x9 board lives as 96 signed bytes in LDS for the
+// duration of a kernel (nibble-packed, 48 B, in HBM); piece sets are held as wave-uniform 90-bit
+// bitboards produced by __ballot, and per position the wave builds per-row / per-column bit masks
+// of the occupancy and of the attackers by type (xq_attack.hpp: AttackMaps), so that ray scans and
+// the king-centric legality filter are a handful of bit operations per lane instead of board walks.  Nothing here is a translation of the reference's Python: the behaviour
 // (SURVEY.md Appendix A quirks included) is the contract, checked bit-for-bit against the oracle.
 //
 // Reference behaviour restated: chess_env.py:76-121 (legal moves, order), :123-251 (generators),
@@ -44,31 +44,6 @@ __device__ __forceinline__ int bb_test(const BB &b, int s)
 {
     return (int)(((s < 64) ? (b.lo >> s) : (b.hi >> (s - 64))) & 1ull);
 }
-__device__ __forceinline__ void bb_clear(BB &b, int s)
-{
-    if (s < 64) b.lo &= ~(1ull << s); else b.hi &= ~(1ull << (s - 64));
-}
-__device__ __forceinline__ void bb_set(BB &b, int s)
-{
-    if (s < 64) b.lo |= (1ull << s); else b.hi |= (1ull << (s - 64));
-}
-// `width` bits starting at bit `sh` (width <= 10, sh + width <= 90)
-__device__ __forceinline__ uint32_t bb_field(const BB &b, int sh, int width)
-{
-    uint64_t v;
-    if (sh < 64) {
-        v = b.lo >> sh;
-        if (sh + width > 64) v |= b.hi << (64 - sh);
-    } else {
-        v = b.hi >> (sh - 64);
-    }
-    return (uint32_t)v & ((1u << width) - 1u);
-}
-// row-major board: row r = 9 bits at 9r.  column-major board: column c = 10 bits at 10c.
-__device__ __forceinline__ uint32_t row_bits(const BB &rm, int r) { return bb_field(rm, 9 * r, 9); }
-__device__ __forceinline__ uint32_t col_bits(const BB &cm, int c) { return bb_field(cm, 10 * c, 10); }
-__device__ __forceinline__ int cm_index(int s) { return (s % 9) * 10 + s / 9; }
-
 // Wave-uniform view of a board held in LDS (all fields identical in every lane).
 struct BoardView {
     BB occ;              // occupancy, row-major
@@ -86,13 +61,6 @@ __device__ __forceinline__ BoardView load_view(const int8_t *bd)
     v.red.lo = __ballot(v.pA > 0);   v.red.hi = __ballot(v.pB > 0);
     v.blk.lo = __ballot(v.pA < 0);   v.blk.hi = __ballot(v.pB < 0);
     return v;
-}
-
-// piece on square s (s wave-uniform) out of the per-lane registers of a view
-__device__ __forceinline__ int view_piece(const BoardView &v, int s)
-{
-    s = uni(s);
-    return (s < 64) ? __builtin_amdgcn_readlane(v.pA, s) : __builtin_amdgcn_readlane(v.pB, s - 64);
 }
 
 __device__ __forceinline__ bool in_palace(int X, int r, int c)

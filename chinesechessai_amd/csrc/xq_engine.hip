@@ -725,17 +725,18 @@ __device__ __forceinline__ void record_leaf(const Eng &E, int slot, WaveLds &L, 
     if (planes) write_planes(bd, side, planes, fmt, slot);
     if (st && lane == 0) st[8] = __builtin_amdgcn_s_memtime();
     const uint64_t h = (E.dedupe || E.ec_on) ? position_hash(my_dword, side) : 0ull;
+    DedupeLook look{ 0u, 0ull };
+    if (E.dedupe) look = dedupe_prepare(E, slot, my_dword, side, h);        // (board + side past the L2s, first look at the table)
     int ec = -1;
     if (E.ec_on) {
-        if (E.dedupe) {                                       // (the board must be there for the wave that fills the entry)
-            if (lane < 12) __hip_atomic_store(&E.leaf_board[(size_t)slot * 12 + lane], my_dword, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (lane == 0) __hip_atomic_store(&E.leaf_side[slot], (int8_t)side, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        ec = eval_cache_probe(E, h, my_dword, side);
+        // a dedupe entry of this round under this hash: most likely this very position, inserted by a wave whose probe of
+        // the cache missed a moment ago - do not queue up behind it on the same cache entry (in the opening thousands would)
+        const bool likely_dup = E.dedupe && (unsigned)(look.ent >> 32) == E.dd_tag;
+        if (!likely_dup) ec = eval_cache_probe(E, h, my_dword, side);
         if (lane == 0) E.leaf_ec[slot] = ec;
     }
     // (last: the planes' stores travel while it waits for the table; a leaf the cache answers needs no row at all)
-    if (E.dedupe && (ec < 0 || E.ec_on == 2)) dedupe_finish(E, slot, my_dword, side, dedupe_prepare(E, slot, my_dword, side, h));
+    if (E.dedupe && (ec < 0 || E.ec_on == 2)) dedupe_finish(E, slot, my_dword, side, look);
     if (st && lane == 0) st[9] = __builtin_amdgcn_s_memtime();
 }
 
@@ -757,17 +758,12 @@ template <bool VL>
 __device__ void search_round_generic(const Eng &E, WaveLds &L, int round, int batch_count, int eval_kind,
                                      const void *ev_a, const void *ev_v, void *planes, int fmt)
 {
-    constexpr bool STAMP = false;
-    unsigned long long *const stamps = nullptr;
     const int g = blockIdx.x, lane = XQ_LANE;
-    XQ_STAMP(0);
     const GameS gs = load_gs(E.gs + g);
     if (gs.done) return;
-    XQ_STAMP(1);
     const Tree T = tree_of(E, g);
     const int K = VL ? E.leaf_slots : 1;             // pending-leaf slots of this game: g * K + k
     int root = 0;
-    unsigned long long *const stp = nullptr;
 
     if (round == 0 && E.eval_carry && E.root_ready[g]) return;     // k_play_move already built this ply's expanded root
     if (round == 0) {
@@ -797,11 +793,9 @@ __device__ void search_round_generic(const Eng &E, WaveLds &L, int round, int ba
         for (int k = 0; k < K; k++)
             consume_eval<VL>(E, g, g * K + k, L, T, root, eval_kind, ev_a, ev_v, gs.n_plies);
     }
-    XQ_STAMP(2);
 
     unpack_to_lds(E.board + (size_t)g * 12, L.root_bd);
     wave_sync();
-    XQ_STAMP(3);
 
     int sims_left = batch_count;
     int nslot = 0;                                   // VL: slots handed out in this round
@@ -815,7 +809,6 @@ __device__ void search_round_generic(const Eng &E, WaveLds &L, int round, int ba
             depth++;
         }
         wave_sync();
-        XQ_STAMP(4);
         int flags = T.fl[node];
         if (VL && !(flags & F_TERM) && T.vl[node] != 0) {
             // this leaf is already waiting for the network in one of this round's slots: one more
@@ -832,7 +825,7 @@ __device__ void search_round_generic(const Eng &E, WaveLds &L, int round, int ba
             if (node == root) {
                 // the root is never terminal (the driver checked legal moves, self_play.py:205-208)
                 record_leaf(E, g * K + nslot, L, L.root_bd, gs.side, root, 0, VL ? 1 : sims_left,
-                            E.root_moves + (size_t)g * MAXM, gs.n_root, planes, fmt, stp);
+                            E.root_moves + (size_t)g * MAXM, gs.n_root, planes, fmt);
                 if (!VL) return;
                 if (lane == 0) T.vl[root] += 1;
                 mem_fence_wave();
@@ -841,7 +834,6 @@ __device__ void search_round_generic(const Eng &E, WaveLds &L, int round, int ba
                 continue;
             }
             // ---- replay the path on a copy of the root env (_copy_env, self_play.py:156-175)
-            if (STAMP && lane == 0 && (flags & 1) == 0) stp[5] = __builtin_amdgcn_s_memtime();      // (flags: depends on the load)
             for (int s = lane; s < 24; s += 64)
                 reinterpret_cast<uint32_t *>(L.bd)[s] = reinterpret_cast<const uint32_t *>(L.root_bd)[s];
             wave_sync();
@@ -865,19 +857,17 @@ __device__ void search_round_generic(const Eng &E, WaveLds &L, int round, int ba
                 st.side = -st.side;
                 st.move_count += 1;
             }
-            XQ_STAMP(6);
             MoveResult mr;
             if (E.want_check)
                 mr = wave_make_move<false, true>(L.bd, st, L.path_move[depth - 1], hist, L.maps, L.cand, L.legal, L.own_sq);
             else
                 mr = wave_make_move<false, false>(L.bd, st, L.path_move[depth - 1], hist, L.maps, L.cand, L.legal, L.own_sq);
             flags |= mr.is_check ? F_CHECK : 0;
-            XQ_STAMP(7);
             const bool terminal = (mr.n_legal == 0) || (st.winner != WINNER_NONE);     // self_play.py:126
             if (!terminal) {
                 if (lane == 0) T.fl[node] = (uint8_t)flags;
                 record_leaf(E, g * K + nslot, L, L.bd, st.side, node, depth, VL ? 1 : sims_left, L.legal, mr.n_legal,
-                            planes, fmt, stp);
+                            planes, fmt);
                 if (!VL) return;
                 if (lane <= depth) { const int x = lane == 0 ? root : L.path_node[lane - 1]; T.vl[x] += 1; }
                 mem_fence_wave();
@@ -1260,7 +1250,10 @@ __device__ void search_round_one(const Eng &E, WaveLds &L, int round, int batch_
                 const uint32_t bdw = lane < 12 ? pack_dword(L.bd, lane) : 0u;
                 int ec = -1;
                 if (E.ec_on) {
-                    ec = eval_cache_probe(E, h, bdw, leaf_side, ec_first, true);
+                    // (a dedupe entry of this round under this hash: most likely this position, inserted by a wave whose
+                    // cache probe has just missed - do not queue up behind it on the same cache entry)
+                    const bool likely_dup = E.dedupe && (unsigned)(look.ent >> 32) == E.dd_tag;
+                    if (!likely_dup) ec = eval_cache_probe(E, h, bdw, leaf_side, ec_first, true);
                     if (lane == 0) E.leaf_ec[slot] = ec;
                 }
                 if (E.dedupe && (ec < 0 || E.ec_on == 2)) dedupe_finish(E, slot, bdw, leaf_side, look);
@@ -2424,7 +2417,9 @@ static int g_search_occ = 4;      // 128 VGPRs, 4 waves/SIMD: fastest of {3, 4, 
 extern "C" void xq_engine_set_search_occupancy(int waves_per_simd) { g_search_occ = waves_per_simd; }
 // diagnostic (include/xq_debug.h): device buffer of 16 u64 per game for k_search_round's phase stamps (probes library
 // only; NULL = off).  Every launch overwrites it: read it after the round of interest.
+#if XQ_TOWER_PROBES
 static void *g_search_stamps = nullptr;
+#endif
 extern "C" int xq_engine_set_search_stamps(void *dev_u64x16_per_game)
 {
 #if XQ_TOWER_PROBES

@@ -317,10 +317,12 @@ __global__ __launch_bounds__(256) void k_value_head(const uint16_t *__restrict__
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is per device: remembered per device ordinal (a process may drive
 // several GPUs, xq_config.device)
-// -1 / 0 = k_policy_fc (8 waves, HIP: the product), 1 = k_policy_fc1w.  k_policy_fc1w takes 152-156 us where k_policy_fc takes 175-200
-// (16,384 rows, alternating in one process), and the self-play step is 0.6 % LONGER with it: the trunk kernel that runs around it
-// then holds 2.10 instead of 2.145 GHz (profiles/r04c_ab_policy_fc.txt; DVFS give-back) - so the default is
-// the kernel that is slower on its own.
+// -1 / 1 = k_policy_fc1w (one wave per SIMD, generated asm body: the product since round 5), 0 = k_policy_fc (8 waves, HIP).
+// Same bits.  k_policy_fc1w takes 152-156 us where k_policy_fc takes 175-200 (16,384 rows, alternating in one process).  Round 4
+// kept the slower kernel as the default: on one box the self-play step was 0.6 % LONGER with the faster one (the trunk kernel
+// around it held a lower clock), on another +0.6 / -1.0 %.  Round 5 repeated the alternation (5 pairs of 5 steps) on a fast box
+// (trunk at 2.16 GHz) and on a slow one (2.06 GHz): +0.95 % and +0.85 % for k_policy_fc1w, every pair, spread +- 0.1 %
+// (profiles/r05_ab_policy_fc.txt, r05c_ab_policy_fc.txt) - the kernel's own saving arrives in full.
 static int g_fc_variant = -1;
 // diagnostic switch (include/xq_debug.h): both kernels compute the same bits
 extern "C" void xq_policy_fc_set_variant(int v) { g_fc_variant = v; }
@@ -376,7 +378,7 @@ extern "C" int xq_policy_fc_bf16(void *stream, const void *act, const void *w, c
     }
 #endif
     if (g_fc_variant > 1) return XQ_E_INVALID;
-    if (g_fc_variant == 1)
+    if (g_fc_variant != 0)
         hipLaunchKernelGGL(k_policy_fc1w<0>, dim3(ntiles), dim3(256), XQ_FC1W_LDS_BYTES, reinterpret_cast<hipStream_t>(stream), a);
     else
         hipLaunchKernelGGL(k_policy_fc<0>, dim3(ntiles), dim3(512), FC_LDS_BYTES, reinterpret_cast<hipStream_t>(stream), a);

@@ -50,11 +50,9 @@ int  xq_conv3x3_debug_stamps(int variant, int ablate, void *hip_stream, const vo
                              const void *bias_dev, const void *residual_dev, void *y_dev, int n_boards, int relu,
                              void *stamps_dev);
 
-/* Kernel behind xq_policy_fc_bf16 (process-wide): -1 or 0 = k_policy_fc (8 waves, HIP: the product), 1 = k_policy_fc1w (one
- * wave per SIMD, generated asm body: 13-20 % faster on its own, 0.6 % slower end to end - the trunk kernel's clock pays for it,
- * DESIGN.md section 5).  Same bits.  2..6 = other DMA placements and timing-only bodies of k_policy_fc1w in a
- * -DXQ_TOWER_PROBES=1 library (3, 4: wrong results); in the default library xq_policy_fc_bf16 answers XQ_E_INVALID while one
- * of them is selected. */
+/* Kernel behind xq_policy_fc_bf16 (process-wide): -1 or 1 = k_policy_fc1w (one wave per SIMD, generated asm body: the product
+ * since round 5), 0 = k_policy_fc (8 waves, HIP).  Same bits.  2..6 = other DMA placements and timing-only bodies of
+ * k_policy_fc1w in a library built with -DXQ_TOWER_PROBES=1 (wrong results; XQ_E_INVALID from xq_policy_fc_bf16 otherwise). */
 void xq_policy_fc_set_variant(int variant);
 
 /* xq_policy_fc_bf16 with a timing-only body (wrong results): ablate 1 = no operand DMA behind the first two K-stages (what

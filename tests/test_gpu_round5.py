@@ -272,7 +272,7 @@ def test_eval_cache_verify_mode_at_the_bench_size(L):
         eng.close()
         assert int(b.error.sum()) == 0
         assert bad == 0, (dedupe, carry, compared, fills, bad)
-        assert compared > 50000 and fills > 50000, (compared, fills)
+        assert compared > (20000 if dedupe else 50000) and fills > 50000, (compared, fills)     # (a likely dedupe duplicate does not look the cache up)
         if not carry:
             # every root of plies 1.. was a leaf of the ply before: the cache knows it
             assert compared >= G * (P - 1), compared
