@@ -192,6 +192,8 @@ def main():
                          "per GPU through the --games concurrent slots, a finished game's slot being refilled with the next seed")
     ap.add_argument("--profile-plies", type=int, default=0,
                     help="profiling aid only: stop every step after this many plies (the JSON line is then NOT a benchmark)")
+    ap.add_argument("--event-stride", type=int, default=4,
+                    help="HIP events around every N-th network forward / trunk launch / k_search_round of the timed region (1 = all)")
     ap.add_argument("--no-eval-cache", action="store_true",
                     help="switch the evaluation cache (position -> priors + value, kept two plies) off")
     ap.add_argument("--no-leaf-dedupe", action="store_true",
@@ -405,26 +407,35 @@ def run_rank(args):
 
     # network forward / trunk kernel timed with events on their own (= the engine's) stream
     class Timed:
-        def __init__(self, ev):
-            self.ev, self.fw, self.tower = ev, [], []
+        """HIP events (on the engine's stream) around every `stride`-th network forward and its trunk launch: an event pair is
+        a marker in the GPU's queue and not free (value_without_event_timing), and 1 forward in 4 of ~1,500 is sample enough;
+        stride and the 7 rounds of a ply are coprime, so every round index is sampled equally often"""
+        def __init__(self, ev, stride):
+            self.ev, self.fw, self.tower, self.idx, self.count, self.stride = ev, [], [], [], 0, max(1, stride)
             self.orig = ev.evaluate
 
         def on(self, timed):
             if timed:
                 def timed_eval(engine):
+                    i = self.count
+                    self.count += 1
+                    if i % self.stride:
+                        self.ev.inet.tower_events = None
+                        return self.orig(engine)
+                    self.ev.inet.tower_events = self.tower
                     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     a.record()
                     out = self.orig(engine)
                     b.record()
                     self.fw.append((a, b))
+                    self.idx.append(i)
                     return out
                 self.ev.evaluate = timed_eval
-                self.ev.inet.tower_events = self.tower
             else:
                 self.ev.evaluate = self.orig
                 self.ev.inet.tower_events = None
 
-    tm = Timed(ev)
+    tm = Timed(ev, args.event_stride)
     TG = args.refill if args.refill else G                  # games per GPU and step
     if args.refill and (args.refill < G or args.temp_cutoff or args.tree_reuse):
         sys.exit("bench.py: --refill TOTAL needs TOTAL >= --games and no per-ply temperature schedule / tree reuse")
@@ -482,7 +493,7 @@ def run_rank(args):
     sync()
     eng.row_history(cap=0, reset=True)
     eng.eval_cache_stats(reset=True)
-    eng.profile(True)
+    eng.profile(max(1, args.event_stride))
     tm.on(True)
     # shader clock held while the trunk kernel runs: one workgroup in 64 adds its cycles / 100 MHz ticks (xq_debug.h)
     clock_buf = torch.zeros(3, dtype=torch.int64, device="cuda")
@@ -504,9 +515,15 @@ def run_rank(args):
     ec_hits_timed = eng.eval_cache_stats(reset=True)[0] if eng.eval_cache else 0
     carry_on = eng._carry_on
     rows_hist, n_rounds = eng.row_history(reset=True) if eng.row_compaction else (None, 0)
-    fw_t = np.array([a.elapsed_time(b) for a, b in tm.fw])
+    fw_t = np.array([a.elapsed_time(b) for a, b in tm.fw])          # the sampled forwards (tm.idx: which ones)
     tw_t = np.array([a.elapsed_time(b) for a, b in tm.tower])
-    fw_ms, n_fw = float(fw_t.sum()), len(fw_t)
+    n_fw, fw_idx = tm.count, np.array(tm.idx, dtype=np.int64)
+    fw_scale = n_fw / max(len(fw_t), 1)                             # sampled -> all forwards
+    fw_ms = float(fw_t.sum()) * fw_scale
+    # the tree kernel: every args.event_stride-th launch was timed; one k_search_round per forward
+    if prof["search_launches"] > 0 and n_fw > 0:
+        prof["search_ms"] *= n_fw / prof["search_launches"]
+        prof["search_launches_timed"], prof["search_launches"] = prof["search_launches"], n_fw
     outcomes = step.outcomes if args.refill else eng.read_game_outcomes()
     t = torch.tensor([dt], dtype=torch.float64, device="cuda")
     if use_dist:
@@ -524,6 +541,9 @@ def run_rank(args):
                 step(eng, ev_, base + k * TG)
             torch.cuda.synchronize()
             return TG * args.aux_steps / (time.time() - ta)
+        # the headline configuration once more without the per-launch HIP events of the timed region (4 per forward + 2 per
+        # tree launch: what the instrumentation itself costs)
+        aux["value_without_event_timing"] = timed_steps(ev, 6_100_000)
         ev_nd = make_ev(args.policy_columns, False) if ev.leaf_dedupe else ev
         if ev.leaf_dedupe:
             step(eng, ev_nd, 7_000_000)                                # (untimed: first step after the switch)
@@ -540,17 +560,16 @@ def run_rank(args):
             del ev_all
         del ev_nd
         if ev.eval_cache:
-            # the evaluation cache (position -> priors + value, two plies): random-init priors are 0.35 % apart, a search
-            # never descends twice into the same child, nothing below the played move is expanded - the cache can answer next
-            # to nothing in the headline workload, notices that after its first step and suspends itself (its probe costs the
-            # tree kernel ~10 %: value_eval_cache_forced_on).  What it is for is a TRAINED network, whose search follows
-            # lines: the same architecture with the policy head's weights and bias scaled by 256 (seeded random-init
-            # otherwise: the top move then holds ~0.9 of the prior mass), with the cache and without
+            # the evaluation cache (position -> priors + value, two plies).  Random-init priors are 0.35 % apart, a search never
+            # descends twice into the same child and nothing below the played move is expanded: what the cache answers in the
+            # headline workload are the transpositions of the opening plies (~2 % of the rows).  What it is for is a TRAINED
+            # network, whose search follows lines: the same architecture with the policy head's weights and bias scaled by
+            # 256 (seeded random-init otherwise: the top move then holds ~0.9 of the prior mass), with the cache and without
             import copy
-            ev_on = make_ev(args.policy_columns, ev.leaf_dedupe, eval_cache="on")
-            step(eng, ev_on, 10_000_000)
-            aux["value_eval_cache_forced_on"] = timed_steps(ev_on, 10_100_000)
-            del ev_on
+            ev_off = make_ev(args.policy_columns, ev.leaf_dedupe, eval_cache=False)
+            step(eng, ev_off, 10_000_000)
+            aux["value_no_eval_cache"] = timed_steps(ev_off, 10_100_000)
+            del ev_off
             net_pk = copy.deepcopy(net)
             with torch.no_grad():
                 net_pk.policy_fc.weight.mul_(256.0)
@@ -610,7 +629,7 @@ def run_rank(args):
         fused = bool(args.fused_tower) and ev.inet.use_hip_conv
         if fused:       # k_tower: conv1 + 2*blocks convs + both heads per launch
             per_board = 2.0 * 90 * (16 * 9 * 128 + 2 * args.blocks * 128 * 9 * 128 + 128 * 40)
-            rows_tw = rows_fw if len(tw_t) == len(rows_fw) else np.full(len(tw_t), rows, np.int64)
+            rows_tw = rows_fw[fw_idx] if (len(tw_t) == len(fw_idx) and len(rows_fw) == n_fw) else np.full(len(tw_t), rows, np.int64)
             # full-size launches: (nearly) every slot has a row - a round in which a few games ended on a terminal leaf or
             # are already over still is one; their flops are counted by the rows they really ran
             full = rows_tw >= 0.98 * rows
@@ -622,7 +641,8 @@ def run_rank(args):
             launches = {"full_size": n_conv, "rows_avg_full_size": float(rows_tw[full].mean()) if n_conv else None,
                         "empty": int((rows_tw == 0).sum()), "partial": int(((rows_tw > 0) & ~full).sum()),
                         "empty_ms_avg": float(tw_t[rows_tw == 0].mean()) if (rows_tw == 0).any() else None,
-                        "all_launches": int(len(tw_t)), "all_ms": float(tw_t.sum())}
+                        "timed_launches": int(len(tw_t)), "timed_every": tm.stride, "all_launches": int(n_fw),
+                        "all_ms": float(tw_t.sum()) * fw_scale}
             tv = args.tower_variant if args.tower_variant >= 0 else (60 if rows >= 2048 else 36)
             kbuild = {60: "k_tower1wa (one wave per SIMD, 4 boards per workgroup, the residual tower as one hand-written asm statement)",
                       39: "k_tower16b<NB = 4>", 36: "k_tower16b<NB = 2>", 0: "k_tower (32x32x16)"}.get(tv, "variant %d" % tv)
@@ -668,8 +688,8 @@ def run_rank(args):
                           "the figure with one row per pending leaf)" % (int(rows_fw.sum()), n_fw))
         if ev.eval_cache:
             extras.append("; evaluation cache (result-identical, tested: a position's priors and value are kept for two plies and answer "
-                          "for any later leaf that is the same position) %s; value_eval_cache_forced_on is the figure with it "
-                          "always on, value_peaked_priors / _no_reuse show what it is for" % (
+                          "for any later leaf that is the same position) %s; value_no_eval_cache is the figure without it (taken "
+                          "like value_without_event_timing: no per-launch events), value_peaked_priors / _no_reuse show what it is for" % (
                               "ON: %d leaves answered in this run" % ec_hits_timed if ec_cache_was_on else
                               "adaptive: it answered %s in its last step (random-init priors make the search revisit next to "
                               "nothing; an answer saves a row, the probe costs the tree kernel ~10 %%) and suspended itself for the timed steps" % (
@@ -697,25 +717,26 @@ def run_rank(args):
             "roofline": {"bound": "mfma", "achieved": conv_tflops, "peak": MFMA_PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": conv_tflops / MFMA_PEAK_BF16_TFLOPS,
                          "traffic": tr_tower[0], "traffic_source": tr_tower[1],
-                         "kernel": "%s (%s; %d full-size launches of %d boards on average, %.4f ms avg; %.0f%% of the step)" % (
-                             kname, kdesc, n_conv, int(round(conv_fl / (per_board if fused else conv_fl / rows))), conv_ms / max(n_conv, 1),
-                             100.0 * conv_ms / (dt * 1e3)),
+                         "kernel": "%s (%s; %d full-size launches timed - HIP events around 1 launch in %d - of %d boards on average, %.4f ms avg; %.0f%% of the step)" % (
+                             kname, kdesc, n_conv, tm.stride, int(round(conv_fl / (per_board if fused else conv_fl / rows))), conv_ms / max(n_conv, 1),
+                             100.0 * conv_ms * fw_scale / (dt * 1e3)),
                          "flops_per_launch": conv_fl, "launches": launches,
                          "clock_ghz": trunk_clock_ghz,
                          "clock_note": "shader clock the chip held inside the trunk kernel over the timed region (s_memtime / s_memrealtime "
                                        "of one workgroup in 64, k_tower1wa only); 2.4 GHz is the peak's clock: frac = MFMA-pipe efficiency x clock / 2.4"},
             "roofline_net": {"bound": "mfma", "achieved": net_tflops, "peak": MFMA_PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                              "frac": net_tflops / MFMA_PEAK_BF16_TFLOPS, "traffic": None,
-                             "kernel": "whole network forward (%d launches, %d rows evaluated in all, %.3f ms avg over all launches)" % (
-                                 n_fw, int(rows_fw.sum()), fw_ms / max(n_fw, 1)),
+                             "kernel": "whole network forward (%d launches, %d rows evaluated in all, %.3f ms avg over all launches, estimated from the 1 in %d that carry events)" % (
+                                 n_fw, int(rows_fw.sum()), fw_ms / max(n_fw, 1), tm.stride),
                              "flops_per_row": fl, "rows_evaluated": int(rows_fw.sum()), "note": rows_note},
             # the whole step against the MFMA peak: every network row evaluated x its flops, over the WALL time of the timed region
             # (per GPU: rank 0's rows over the max-over-ranks time against ONE GPU's peak; every rank plays the same number of games)
             "end_to_end_mfma_frac": float(fl * rows_fw.sum()) / dt / 1e12 / MFMA_PEAK_BF16_TFLOPS,
             "roofline_tree": {"bound": "hbm", "achieved": tree_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": tree_gbs / HBM_PEAK_GBS, "traffic": tr_tree[0], "traffic_source": tr_tree[1],
-                              "kernel": "k_search_round (%d launches, %.3f ms avg)" % (
-                                  prof["search_launches"], prof["search_ms"] / max(prof["search_launches"], 1)),
+                              "kernel": "k_search_round (%d launches, %d of them timed, %.3f ms avg)" % (
+                                  prof["search_launches"], prof.get("search_launches_timed", prof["search_launches"]),
+                                  prof["search_ms"] / max(prof["search_launches"], 1)),
                               "bytes_per_launch": tree_bytes / max(n_search, 1),
                               "bytes_note": "%d launches that descend (%.0f B per game: board + scalars, PUCT reads, leaf moves / board / planes, "
                                             "logit gather, edge init, backup%s) + %d launches of round 0 under the carry-over (64 B per game)" % (

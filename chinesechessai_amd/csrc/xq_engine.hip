@@ -633,8 +633,13 @@ __device__ __forceinline__ DedupeLook dedupe_prepare(const Eng &E, int slot, uin
 // look on its way before the move generation: one of the probe's two memory round trips is then hidden).
 __device__ __forceinline__ unsigned eval_cache_pos(const Eng &E, uint64_t h) { return (unsigned)(h >> 24) & (unsigned)E.ec_mask; }
 
+//
+// `crowded` (wave-uniform): the dedupe table already holds an entry of this round under this position's hash - most likely
+// this very position, put there by a wave whose own probe has just reserved the cache entry (in the opening thousands of
+// waves arrive with one position).  Such a leaf still takes an answer the cache HAS, but does not join the race for an
+// entry that is free: 16,384 compare-and-swaps on one word cost more than the cache saves.
 __device__ __forceinline__ int eval_cache_probe(const Eng &E, uint64_t h, uint32_t my_dword, int side,
-                                                unsigned long long first = 0ull, bool have_first = false)
+                                                unsigned long long first = 0ull, bool have_first = false, bool crowded = false)
 {
     const int lane = XQ_LANE;
     const unsigned mask = (unsigned)E.ec_mask, epoch = E.ec_epoch, seq = E.ec_seq;
@@ -644,6 +649,7 @@ __device__ __forceinline__ int eval_cache_probe(const Eng &E, uint64_t h, uint32
         const unsigned long long st = uni64(raw);
         const unsigned ep = (unsigned)(st >> 32), filled = (unsigned)st;
         if (epoch - ep > 1u) {                                  // older than the ply before this one (or never used): take it
+            if (crowded) return -1;
             unsigned long long old = 0;
             if (lane == 0) old = atomicCAS(&E.ec_state[pos], st, ((unsigned long long)epoch << 32) | 0xffffffffull);
             old = uni64(old);
@@ -729,10 +735,7 @@ __device__ __forceinline__ void record_leaf(const Eng &E, int slot, WaveLds &L, 
     if (E.dedupe) look = dedupe_prepare(E, slot, my_dword, side, h);        // (board + side past the L2s, first look at the table)
     int ec = -1;
     if (E.ec_on) {
-        // a dedupe entry of this round under this hash: most likely this very position, inserted by a wave whose probe of
-        // the cache missed a moment ago - do not queue up behind it on the same cache entry (in the opening thousands would)
-        const bool likely_dup = E.dedupe && (unsigned)(look.ent >> 32) == E.dd_tag;
-        if (!likely_dup) ec = eval_cache_probe(E, h, my_dword, side);
+        ec = eval_cache_probe(E, h, my_dword, side, 0ull, false, E.dedupe && (unsigned)(look.ent >> 32) == E.dd_tag);
         if (lane == 0) E.leaf_ec[slot] = ec;
     }
     // (last: the planes' stores travel while it waits for the table; a leaf the cache answers needs no row at all)
@@ -1250,10 +1253,7 @@ __device__ void search_round_one(const Eng &E, WaveLds &L, int round, int batch_
                 const uint32_t bdw = lane < 12 ? pack_dword(L.bd, lane) : 0u;
                 int ec = -1;
                 if (E.ec_on) {
-                    // (a dedupe entry of this round under this hash: most likely this position, inserted by a wave whose
-                    // cache probe has just missed - do not queue up behind it on the same cache entry)
-                    const bool likely_dup = E.dedupe && (unsigned)(look.ent >> 32) == E.dd_tag;
-                    if (!likely_dup) ec = eval_cache_probe(E, h, bdw, leaf_side, ec_first, true);
+                    ec = eval_cache_probe(E, h, bdw, leaf_side, ec_first, true, E.dedupe && (unsigned)(look.ent >> 32) == E.dd_tag);
                     if (lane == 0) E.leaf_ec[slot] = ec;
                 }
                 if (E.dedupe && (ec < 0 || E.ec_on == 2)) dedupe_finish(E, slot, bdw, leaf_side, look);
@@ -2027,7 +2027,8 @@ struct xq_engine {
     unsigned dd_tag = 0;                      // round tag of the leaf dedupe table (never 0: the cleared table's tag)
     unsigned ec_epoch = 16, ec_seq = 0;       // evaluation cache: ply counter (+2 at every new set of roots), launch counter
     // profiling
-    bool prof = false;
+    int prof = 0;                             // 0 = off, N = HIP events around every N-th k_search_round (and every k_play_move)
+    unsigned prof_seen = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_search, ev_play;
     size_t ev_search_used = 0, ev_play_used = 0;
     double search_ms = 0, play_ms = 0;
@@ -2446,7 +2447,7 @@ extern "C" int xq_engine_search_round(xq_engine *e, int round, int eval_kind, co
     const int start = round * e->E.leaf_batch;
     const int batch = (start + e->E.leaf_batch <= e->E.sims) ? e->E.leaf_batch : e->E.sims - start;
     std::pair<hipEvent_t, hipEvent_t> *ev = nullptr;
-    if (e->prof) {
+    if (e->prof && (e->prof_seen++ % (unsigned)e->prof) == 0) {
         if (e->ev_search_used >= 4096) { if (int rc = drain_events(e)) return rc; }
         ev = next_events(e->ev_search, e->ev_search_used);
         if (ev) HIPCHK(hipEventRecord(ev->first, e->stream));
@@ -2956,7 +2957,8 @@ extern "C" int xq_engine_profile(xq_engine *e, int enable)
 {
     if (!e) return fail(XQ_E_INVALID, "null engine");
     if (int rc = drain_events(e)) return rc;
-    e->prof = enable != 0;
+    e->prof = enable > 0 ? enable : 0;        // (enable = N > 1: every N-th search launch is timed - an event pair is not free)
+    e->prof_seen = 0;
     if (enable) { e->search_ms = e->play_ms = 0; e->search_n = e->play_n = 0; }
     return 0;
 }

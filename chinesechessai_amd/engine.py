@@ -113,13 +113,13 @@ class TorchNetEvaluator:
         self.leaf_dedupe = bool(leaf_dedupe and self.row_compaction)
         # ... and a position evaluated during the last two plies - by any game - need not be evaluated again
         # (SelfPlayEngine.set_eval_cache; `eval_cache=False` evaluates every leaf the reference would)
-        # eval_cache: True = on, and it watches itself: its probe costs the tree kernel ~10 % (0.6-1 % of a step with the
-        # 6-block network) and an answered leaf saves one network row - but with random-init weights the answers (2 % of
-        # the rows at 16,384 games) all fall into the first plies, whose launches the leaf dedupe has already emptied: the
-        # step gets 0.6-1 % SLOWER (measured).  So a whole play() in which it answered fewer leaves than 5 % of the rows
-        # that were evaluated suspends it for the next 15 plays with this evaluator, then it tries again (a trained
-        # network's line-following search: 40-60 %).  "on" = always on; False = off; "verify" = leaves the cache could
-        # answer are evaluated all the same and compared with its entry
+        # eval_cache: True = on, and it watches itself: its probe costs the tree kernel a few per cent and an answered leaf
+        # saves one network row.  With random-init weights at 16,384 games it answers ~2 % of the rows (transpositions of the
+        # opening plies) and the step gets ~1 % faster (measured, round 5, once likely dedupe duplicates stopped queueing on
+        # one cache entry); a trained network's line-following search: 40-60 % of the rows.  A whole play() in which it
+        # answered fewer leaves than 1 % of the rows that were evaluated suspends it for the next 15 plays with this
+        # evaluator, then it tries again.  "on" = always on; False = off; "verify" = leaves the cache could answer are
+        # evaluated all the same and compared with its entry
         self.eval_cache_verify = eval_cache == "verify"
         self.eval_cache = bool(eval_cache and self.row_compaction)
         self.eval_cache_adaptive = eval_cache is True
@@ -165,7 +165,7 @@ class TorchNetEvaluator:
             played = n_now - self._rounds_at_bind if n_now >= self._rounds_at_bind else n_now     # (the caller may have reset the count)
             rows = int(engine.row_history(cap=max(played, 1))[0].astype(np.int64).sum()) if played > 0 else 0
             self.eval_cache_last = (hits, fills, rows)
-            if self.eval_cache_adaptive and hits < 0.05 * (rows + hits):
+            if self.eval_cache_adaptive and hits < 0.01 * (rows + hits):
                 self.eval_cache_suspended = 15
         elif self.eval_cache_suspended > 0:
             self.eval_cache_suspended -= 1
@@ -621,7 +621,8 @@ class SelfPlayEngine:
         _lib.check(self.L.xq_engine_pack_samples(self.h, C.c_void_p(records_ptr)))
 
     def profile(self, enable):
-        _lib.check(self.L.xq_engine_profile(self.h, 1 if enable else 0))
+        """HIP events around the tree-kernel launches: False / 0 off, True / 1 every launch, N every N-th search round"""
+        _lib.check(self.L.xq_engine_profile(self.h, int(enable)))
 
     def profile_read(self):
         sm, pm = C.c_double(), C.c_double()

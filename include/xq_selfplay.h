@@ -404,7 +404,9 @@ int     xq_replay_encode_batch(void *rb, void *hip_stream, const int64_t *idx_ho
 /* compatibility view: the records at deque indices idx_host[] copied to host memory */
 int     xq_replay_read_records(void *rb, void *hip_stream, const int64_t *idx_host, int batch, void *records_host);
 
-/* ---- measurement: HIP events recorded on the engine's stream around every tree-kernel launch ---- */
+/* ---- measurement: HIP events recorded on the engine's stream around the tree-kernel launches: enable = 0 off, 1 every
+ * launch, N > 1 every N-th xq_engine_search_round (an event pair costs the GPU a few microseconds; every
+ * xq_engine_play_move is timed either way).  _read: sums and counts of the launches that were timed ---- */
 int  xq_engine_profile(xq_engine *e, int enable);
 int  xq_engine_profile_read(xq_engine *e, double *search_ms_total, int64_t *search_launches,
                             double *play_ms_total, int64_t *play_launches);

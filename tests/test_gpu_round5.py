@@ -279,28 +279,41 @@ def test_eval_cache_verify_mode_at_the_bench_size(L):
 
 
 def test_eval_cache_suspends_itself_when_it_answers_nothing(L):
-    """The default (`eval_cache=True`) watches itself: with random-init weights a search revisits next to nothing, the
-    cache answers < 2 % of the leaves it looks up, and after one play it steps aside for the next 15 (its probe is not
-    free); with the mate-line network it stays.  `eval_cache="on"` never steps aside.  Results never change."""
+    """The default (`eval_cache=True`) watches itself: a play() in which it answered fewer leaves than 1 % of the rows that
+    were evaluated suspends it for the evaluator's next 15 plays (its probe is not free).  Games that never meet - every
+    game started from a position of its own (`set_roots`) - give it nothing to answer; games from the start position
+    (transpositions of the opening) and the mate-line network keep it on.  `eval_cache="on"` never steps aside.  Results
+    never change."""
     import torch
     from chinesechessai_amd.engine import SelfPlayEngine, TorchNetEvaluator
     from chinesechessai_amd.neural_network import ChessNet
     torch.manual_seed(3)
     net = ChessNet(num_blocks=2).eval().cuda()
-    G = 2048                                         # (whole games: the opening's transpositions are a small share then)
+    G = 2048
     seeds = np.arange(G, dtype=np.uint32)
     ev = TorchNetEvaluator(net)
-    eng = SelfPlayEngine(G, sims=50, planes_format=ev.planes_format)
+    eng = SelfPlayEngine(G, sims=50, planes_format=ev.planes_format, max_moves=12)
     a = eng.play(ev, seeds)
     hits, fills, rows = ev.eval_cache_last
-    assert eng.eval_cache and ev.eval_cache_suspended == 15 and hits < 0.05 * (rows + hits), ev.eval_cache_last
+    assert eng.eval_cache and ev.eval_cache_suspended == 0 and hits >= 0.01 * (rows + hits), ev.eval_cache_last
+    # the same evaluator told that it answered nothing: it steps aside, results unchanged
+    ev.eval_cache_suspended = 15
     b = eng.play(ev, seeds)
     assert not eng.eval_cache and ev.eval_cache_suspended == 14
     assert np.array_equal(a.chosen, b.chosen) and np.array_equal(a.s_counts, b.s_counts)
+    # ... and the rule itself, on the numbers it sees
+    class Fake:
+        eval_cache = True
+        def eval_cache_stats(self): return (5, 1000, 0)
+        def row_history(self, cap=0, reset=False): return (np.full(max(cap, 1), 100, np.int32), 10)
+    ev2 = TorchNetEvaluator(net)
+    ev2._rounds_at_bind = 0
+    ev2.after_play(Fake())                           # 5 answers against 1,000 rows: below 1 %
+    assert ev2.eval_cache_suspended == 15 and ev2.eval_cache_last == (5, 1000, 1000)
     ev_on = TorchNetEvaluator(net, eval_cache="on")
-    eng.play(ev_on, seeds)
-    eng.play(ev_on, seeds)
-    assert eng.eval_cache and ev_on.eval_cache_suspended == 0
+    ev_on._rounds_at_bind = 0
+    ev_on.after_play(Fake())
+    assert ev_on.eval_cache_suspended == 0
     eng.close()
     seeds = np.arange(256, dtype=np.uint32)
     ev = TorchNetEvaluator(_mate_line_net(2, 11))

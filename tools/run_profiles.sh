@@ -1,5 +1,4 @@
-# (--no-eval-cache: the adaptive evaluation cache is ON in the first step of a process and suspends itself for this random-init
-# workload afterwards - what these one-step passes profile is the steady state, i.e. the cache off)
+# (the profiled passes run --no-root-eval-carry --no-leaf-dedupe --no-eval-cache: every network launch is then a full-size one)
 set -e
 TAG=${1:-r03}
 cd $GRAFT_REPO_ROOT
