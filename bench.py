@@ -501,8 +501,11 @@ def run_rank(args):
     _lib.lib().xq_tower_set_clock_sample(clock_buf.data_ptr())
     try:
         t0 = time.time()
+        ec_hits_timed = 0
         for k in range(args.steps):
             step(eng, ev, k * TG * world)
+            if eng.eval_cache and ev.eval_cache_last is not None:       # (bind() starts the counts afresh every step)
+                ec_hits_timed += int(ev.eval_cache_last[0])
         sync()
         dt = time.time() - t0
     finally:                # (the library keeps a raw pointer: never leave it behind, whatever the timed loop did)
@@ -512,7 +515,7 @@ def run_rank(args):
     trunk_clock_ghz = float(clk[0]) / float(clk[1]) * 0.1 if clk[1] > 0 else None
     prof = eng.profile_read()
     ec_cache_was_on = bool(eng.eval_cache)
-    ec_hits_timed = eng.eval_cache_stats(reset=True)[0] if eng.eval_cache else 0
+    eng.eval_cache_stats(reset=True)
     carry_on = eng._carry_on
     rows_hist, n_rounds = eng.row_history(reset=True) if eng.row_compaction else (None, 0)
     fw_t = np.array([a.elapsed_time(b) for a, b in tm.fw])          # the sampled forwards (tm.idx: which ones)
