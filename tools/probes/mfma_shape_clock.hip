@@ -1,0 +1,109 @@
+// Which MFMA shape holds the higher clock under the power limit?  The trunk (k_tower1wa) issues v_mfma_f32_16x16x32_bf16
+// and runs at 2.06-2.19 of 2.4 GHz; v_mfma_f32_32x32x16_bf16 does the same flops per cycle with half the instructions and
+// half the operand-register reads per flop.  This probe runs the trunk's macro tile (96 x 128 accumulators per wave, one
+// wave per SIMD, one workgroup per CU) as a bare issue loop in both shapes, with and without the trunk's LDS operand reads
+// (14 x ds_read_b128 per K = 32), for ~0.3 s each, alternating, and prints TFLOP/s and the shader clock held.
+//   hipcc --offload-arch=gfx950 -O3 -o /tmp/mfma_shape_clock tools/probes/mfma_shape_clock.hip && /tmp/mfma_shape_clock
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+// SHAPE 0: 6 x 8 tiles of 16x16x32; SHAPE 1: 3 x 4 tiles of 32x32x16, two K halves.  LDS: operands re-read every K step.
+template <int SHAPE, bool LDS>
+__global__ __launch_bounds__(256) void k_probe(const uint4 *src, float *sink, unsigned long long *clk, int iters)
+{
+    extern __shared__ uint4 lds[];                               // 2 x 14 fragments x 256 lanes x 16 B = 114,688 B: one workgroup per CU
+    const int t = threadIdx.x;
+    for (int i = t; i < 2 * 14 * 256; i += 256) lds[i] = src[i];
+    __syncthreads();
+    bf16x8 fr[14];
+    for (int f = 0; f < 14; f++) fr[f] = __builtin_bit_cast(bf16x8, lds[f * 256 + t]);
+    f32x4 a16[6][8];
+    f32x16 a32[3][4];
+    for (int m = 0; m < 6; m++) for (int n = 0; n < 8; n++) a16[m][n] = f32x4{0, 0, 0, 0};
+    for (int m = 0; m < 3; m++) for (int n = 0; n < 4; n++) for (int e = 0; e < 16; e++) a32[m][n][e] = 0.f;
+    const bool stamp = (blockIdx.x & 63) == 0 && t == 0;
+    unsigned long long c0 = 0, r0 = 0;
+    if (stamp) { c0 = __builtin_readcyclecounter(); r0 = __builtin_amdgcn_s_memrealtime(); }
+    for (int it = 0; it < iters; it++) {
+        if (LDS) {
+            const int base = (it & 1) * 14 * 256;
+#pragma unroll
+            for (int f = 0; f < 14; f++) fr[f] = __builtin_bit_cast(bf16x8, lds[base + f * 256 + t]);
+        }
+        if (SHAPE == 0) {
+#pragma unroll
+            for (int m = 0; m < 6; m++)
+#pragma unroll
+                for (int n = 0; n < 8; n++)
+                    a16[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[m], fr[6 + n], a16[m][n], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int h = 0; h < 2; h++)
+#pragma unroll
+                for (int m = 0; m < 3; m++)
+#pragma unroll
+                    for (int n = 0; n < 4; n++)
+                        a32[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[h * 3 + m], fr[6 + h * 4 + n], a32[m][n], 0, 0, 0);
+        }
+    }
+    if (stamp) {
+        const unsigned long long c1 = __builtin_readcyclecounter(), r1 = __builtin_amdgcn_s_memrealtime();
+        atomicAdd(&clk[0], c1 - c0);
+        atomicAdd(&clk[1], r1 - r0);
+    }
+    float s = 0.f;
+    if (SHAPE == 0) { for (int m = 0; m < 6; m++) for (int n = 0; n < 8; n++) s += a16[m][n][0] + a16[m][n][3]; }
+    else { for (int m = 0; m < 3; m++) for (int n = 0; n < 4; n++) s += a32[m][n][0] + a32[m][n][15]; }
+    sink[blockIdx.x * 256 + t] = s;
+}
+
+static uint16_t bf16_of(float x) { uint32_t u; memcpy(&u, &x, 4); return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1)) >> 16); }
+
+int main(int argc, char **argv)
+{
+    const double seconds = argc > 1 ? atof(argv[1]) : 0.3;
+    const int reps = argc > 2 ? atoi(argv[2]) : 3;
+    const int n16 = 2 * 14 * 256;
+    std::vector<uint16_t> h(n16 * 8);
+    uint32_t x = 12345u;
+    for (auto &v : h) {                                           // roughly N(0, 1/16): sums of K = 32 stay O(1), nothing overflows
+        float s = 0.f;
+        for (int k = 0; k < 4; k++) { x = x * 1664525u + 1013904223u; s += (float)(x >> 8) / 16777216.f - 0.5f; }
+        v = bf16_of(s * 0.43f);
+    }
+    uint4 *src; float *sink; unsigned long long *clk;
+    const int WG = 256;
+    CHECK(hipMalloc(&src, n16 * 16)); CHECK(hipMalloc(&sink, WG * 256 * 4)); CHECK(hipMalloc(&clk, 16));
+    CHECK(hipMemcpy(src, h.data(), n16 * 16, hipMemcpyHostToDevice));
+    const size_t ldsb = n16 * 16;
+    void (*ks[4])(const uint4 *, float *, unsigned long long *, int) = {k_probe<0, false>, k_probe<1, false>, k_probe<0, true>, k_probe<1, true>};
+    const char *names[4] = {"16x16x32, registers only", "32x32x16, registers only", "16x16x32 + 14 ds_read_b128 per K=32", "32x32x16 + 14 ds_read_b128 per K=32"};
+    for (int c = 0; c < 4; c++) CHECK(hipFuncSetAttribute((const void *)ks[c], hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
+    const double flop_it = 1024.0 * 48 * 16384;                  // per loop iteration over the chip: 1,024 waves x 48 MFMAs' worth
+    const int iters = (int)(seconds * 2.2e15 / flop_it);
+    hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    printf("iterations per launch %d (%.1f TFLOP per launch)\n", iters, iters * flop_it / 1e12);
+    for (int r = 0; r < reps + 1; r++)
+        for (int c = 0; c < 4; c++) {
+            CHECK(hipMemset(clk, 0, 16));
+            CHECK(hipEventRecord(e0));
+            hipLaunchKernelGGL(ks[c], dim3(WG), dim3(256), ldsb, 0, src, sink, clk, iters);
+            CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1)); CHECK(hipGetLastError());
+            float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+            unsigned long long hc[2]; CHECK(hipMemcpy(hc, clk, 16, hipMemcpyDeviceToHost));
+            if (r == 0) continue;                                 // (first pass: warm-up, lets the power controller settle)
+            printf("%-40s %8.2f ms  %7.1f TFLOP/s  %.3f GHz  MFMA-pipe share of cycles %.3f\n", names[c], ms, iters * flop_it / ms / 1e9,
+                   (double)hc[0] / (double)hc[1] * 0.1, iters * 48.0 * 16.0 / ((double)hc[0] / 4.0));
+            fflush(stdout);
+        }
+    return 0;
+}
