@@ -547,8 +547,11 @@ def run_rank(args):
         # the headline configuration once more without the per-launch HIP events of the timed region (4 per forward + 2 per
         # tree launch: what the instrumentation itself costs)
         aux["value_without_event_timing"] = timed_steps(ev, 6_100_000)
-        ev_nd = make_ev(args.policy_columns, False) if ev.leaf_dedupe else ev
-        if ev.leaf_dedupe:
+        # (the no-dedupe and no-carry legs run WITHOUT the evaluation cache too: the cache would answer most of what the other
+        # two eliminations leave behind - a re-evaluated root was a leaf one ply earlier - and the legs are meant to show the
+        # path with one network row per pending leaf)
+        ev_nd = make_ev(args.policy_columns, False, eval_cache=False) if (ev.leaf_dedupe or ev.eval_cache) else ev
+        if ev_nd is not ev:
             step(eng, ev_nd, 7_000_000)                                # (untimed: first step after the switch)
             aux["value_no_dedupe"] = timed_steps(ev_nd, 7_100_000)
         if carry_on:
@@ -595,7 +598,7 @@ def run_rank(args):
                                          "value_peaked_priors = everything on, value_peaked_priors_no_reuse = the evaluation cache "
                                          "off; rows_per_game = network rows evaluated per game")
         aux["aux_note"] = ("games/s over %d extra steps each, same engine, outside the timed region: value_no_dedupe = every "
-                           "pending leaf has its own network row (carry-over on; the round-3a form); value_no_carry = that and "
+                           "pending leaf has its own network row (no dedupe, no evaluation cache; carry-over on: the round-3a form); value_no_carry = that and "
                            "every root evaluated afresh, i.e. the reference's evaluation count, 7 forwards of G rows per ply "
                            "(rounds 1 and 2 of this project quoted this form); value_full_policy_head = policy FC on all 8,100 "
                            "columns (carry-over and dedupe as in the headline)" % args.aux_steps)

@@ -2,7 +2,8 @@
 // and runs at 2.06-2.19 of 2.4 GHz; v_mfma_f32_32x32x16_bf16 does the same flops per cycle with half the instructions and
 // half the operand-register reads per flop.  This probe runs the trunk's macro tile (96 x 128 accumulators per wave, one
 // wave per SIMD, one workgroup per CU) as a bare issue loop in both shapes, with and without the trunk's LDS operand reads
-// (14 x ds_read_b128 per K = 32), for ~0.3 s each, alternating, and prints TFLOP/s and the shader clock held.
+// (14 x ds_read_b128 per K = 32), for ~0.3 s each, alternating, and prints TFLOP/s and the shader clock held.  At full
+// MFMA duty the chip cannot hold its clock: the first line of each pair is the sustained MFMA rate under the power cap.
 //   hipcc --offload-arch=gfx950 -O3 -o /tmp/mfma_shape_clock tools/probes/mfma_shape_clock.hip && /tmp/mfma_shape_clock
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -16,54 +17,32 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
-// SHAPE 0: 6 x 8 tiles of 16x16x32; SHAPE 1: 3 x 4 tiles of 32x32x16, two K halves.  LDS: operands re-read every K step.
-template <int SHAPE, bool LDS>
-__global__ __launch_bounds__(256) void k_probe(const uint4 *src, float *sink, unsigned long long *clk, int iters)
+#include "mfma_shape_clock_body.inc"
+
+// V: 0 = R16, 1 = R32 (operands stay in registers), 2 = L16, 3 = L32 (the other operand set re-read from LDS under the MFMAs:
+// two K = 32 steps per loop pass).  The loops are asm statements with fixed registers (gen_mfma_shape_clock.py).
+template <int V>
+__global__ __launch_bounds__(256) void k_probe(const uint4 *src, float *sink, unsigned long long *clk, int passes)
 {
-    extern __shared__ uint4 lds[];                               // 2 x 14 fragments x 256 lanes x 16 B = 114,688 B: one workgroup per CU
+    extern __shared__ uint4 lds[];                               // 2 banks x 14 fragments x 256 lanes x 16 B = 114,688 B: one workgroup per CU
     const int t = threadIdx.x;
     for (int i = t; i < 2 * 14 * 256; i += 256) lds[i] = src[i];
     __syncthreads();
-    bf16x8 fr[14];
-    for (int f = 0; f < 14; f++) fr[f] = __builtin_bit_cast(bf16x8, lds[f * 256 + t]);
-    f32x4 a16[6][8];
-    f32x16 a32[3][4];
-    for (int m = 0; m < 6; m++) for (int n = 0; n < 8; n++) a16[m][n] = f32x4{0, 0, 0, 0};
-    for (int m = 0; m < 3; m++) for (int n = 0; n < 4; n++) for (int e = 0; e < 16; e++) a32[m][n][e] = 0.f;
     const bool stamp = (blockIdx.x & 63) == 0 && t == 0;
     unsigned long long c0 = 0, r0 = 0;
-    if (stamp) { c0 = __builtin_readcyclecounter(); r0 = __builtin_amdgcn_s_memrealtime(); }
-    for (int it = 0; it < iters; it++) {
-        if (LDS) {
-            const int base = (it & 1) * 14 * 256;
-#pragma unroll
-            for (int f = 0; f < 14; f++) fr[f] = __builtin_bit_cast(bf16x8, lds[base + f * 256 + t]);
-        }
-        if (SHAPE == 0) {
-#pragma unroll
-            for (int m = 0; m < 6; m++)
-#pragma unroll
-                for (int n = 0; n < 8; n++)
-                    a16[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[m], fr[6 + n], a16[m][n], 0, 0, 0);
-        } else {
-#pragma unroll
-            for (int h = 0; h < 2; h++)
-#pragma unroll
-                for (int m = 0; m < 3; m++)
-#pragma unroll
-                    for (int n = 0; n < 4; n++)
-                        a32[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[h * 3 + m], fr[6 + h * 4 + n], a32[m][n], 0, 0, 0);
-        }
-    }
+    if (stamp) { c0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
+    const int a0 = t * 16, a1 = t * 16 + 14 * 4096;
+    float o;
+    if (V == 0) asm volatile(PROBE_BODY_R16 : [o] "=v"(o) : [a0] "v"(a0), [a1] "v"(a1), [n] "s"(passes) : PROBE_CLOBBERS);
+    if (V == 1) asm volatile(PROBE_BODY_R32 : [o] "=v"(o) : [a0] "v"(a0), [a1] "v"(a1), [n] "s"(passes) : PROBE_CLOBBERS);
+    if (V == 2) asm volatile(PROBE_BODY_L16 : [o] "=v"(o) : [a0] "v"(a0), [a1] "v"(a1), [n] "s"(passes) : PROBE_CLOBBERS);
+    if (V == 3) asm volatile(PROBE_BODY_L32 : [o] "=v"(o) : [a0] "v"(a0), [a1] "v"(a1), [n] "s"(passes) : PROBE_CLOBBERS);
     if (stamp) {
-        const unsigned long long c1 = __builtin_readcyclecounter(), r1 = __builtin_amdgcn_s_memrealtime();
+        const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
         atomicAdd(&clk[0], c1 - c0);
         atomicAdd(&clk[1], r1 - r0);
     }
-    float s = 0.f;
-    if (SHAPE == 0) { for (int m = 0; m < 6; m++) for (int n = 0; n < 8; n++) s += a16[m][n][0] + a16[m][n][3]; }
-    else { for (int m = 0; m < 3; m++) for (int n = 0; n < 4; n++) s += a32[m][n][0] + a32[m][n][15]; }
-    sink[blockIdx.x * 256 + t] = s;
+    sink[blockIdx.x * 256 + t] = o;
 }
 
 static uint16_t bf16_of(float x) { uint32_t u; memcpy(&u, &x, 4); return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1)) >> 16); }
@@ -85,18 +64,18 @@ int main(int argc, char **argv)
     CHECK(hipMalloc(&src, n16 * 16)); CHECK(hipMalloc(&sink, WG * 256 * 4)); CHECK(hipMalloc(&clk, 16));
     CHECK(hipMemcpy(src, h.data(), n16 * 16, hipMemcpyHostToDevice));
     const size_t ldsb = n16 * 16;
-    void (*ks[4])(const uint4 *, float *, unsigned long long *, int) = {k_probe<0, false>, k_probe<1, false>, k_probe<0, true>, k_probe<1, true>};
+    void (*ks[4])(const uint4 *, float *, unsigned long long *, int) = {k_probe<0>, k_probe<1>, k_probe<2>, k_probe<3>};
     const char *names[4] = {"16x16x32, registers only", "32x32x16, registers only", "16x16x32 + 14 ds_read_b128 per K=32", "32x32x16 + 14 ds_read_b128 per K=32"};
     for (int c = 0; c < 4; c++) CHECK(hipFuncSetAttribute((const void *)ks[c], hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
     const double flop_it = 1024.0 * 48 * 16384;                  // per loop iteration over the chip: 1,024 waves x 48 MFMAs' worth
-    const int iters = (int)(seconds * 2.2e15 / flop_it);
+    const int iters = (int)(seconds * 2.2e15 / flop_it) & ~1;
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
     printf("iterations per launch %d (%.1f TFLOP per launch)\n", iters, iters * flop_it / 1e12);
     for (int r = 0; r < reps + 1; r++)
         for (int c = 0; c < 4; c++) {
             CHECK(hipMemset(clk, 0, 16));
             CHECK(hipEventRecord(e0));
-            hipLaunchKernelGGL(ks[c], dim3(WG), dim3(256), ldsb, 0, src, sink, clk, iters);
+            hipLaunchKernelGGL(ks[c], dim3(WG), dim3(256), ldsb, 0, src, sink, clk, c >= 2 ? iters / 2 : iters);
             CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1)); CHECK(hipGetLastError());
             float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
             unsigned long long hc[2]; CHECK(hipMemcpy(hc, clk, 16, hipMemcpyDeviceToHost));

@@ -7,7 +7,7 @@ export TMPDIR=/tmp
 O=$GRAFT_REPO_ROOT/gpurun_out
 timeout -k 10 200 python bench.py --games 4096 --sims 15 --blocks 4 --steps 2 --warmup 1 --no-cpu-baseline > $O/${TAG}_bench_c2.json 2> $O/${TAG}_bench_c2.err
 echo "c2 done"
-timeout -k 10 300 python bench.py --sims 200 --blocks 20 --root-noise 0.3,0.25 --temp-cutoff 30 --steps 1 --warmup 0 --no-cpu-baseline > $O/${TAG}_bench_c5_1gpu.json 2> $O/${TAG}_bench_c5.err
+timeout -k 10 500 python bench.py --sims 200 --blocks 20 --root-noise 0.3,0.25 --temp-cutoff 30 --steps 1 --warmup 0 --aux-steps 1 --no-cpu-baseline > $O/${TAG}_bench_c5_1gpu.json 2> $O/${TAG}_bench_c5.err
 echo "c5 done"
 timeout -k 10 300 python bench.py --refill 32768 --steps 1 --warmup 0 --no-cpu-baseline > $O/${TAG}_bench_c3_refill.json 2> $O/${TAG}_bench_refill.err
 echo "refill done"
