@@ -465,6 +465,12 @@ def run_rank(args):
         torch.cuda.synchronize()
 
     eng = SelfPlayEngine(G, sims=S, planes_format=ev.planes_format, device=dev, stream=stream)
+    # (a stride that shares a factor with the rounds of a ply would sample the same round indices over and over - 4 rounds at
+    # 15 simulations against the default stride of 4: only the light round 0 - so it moves up to the next coprime number)
+    import math
+    while args.event_stride > 1 and math.gcd(args.event_stride, eng.rounds) != 1:
+        args.event_stride += 1
+    tm.stride = max(1, args.event_stride)
     if args.no_root_eval_carry:
         eng.set_root_eval_carry(False)
     if args.tree_reuse:
