@@ -13,7 +13,7 @@ ChessEnv = ChineseChess          # BASELINE north_star's name for chess_env.py:9
 
 def __getattr__(name):
     # torch-dependent parts load lazily so that rules-only users do not pay the torch import
-    if name in ("MCTS", "self_play_game", "parallel_self_play", "InterruptedWithResults", "SelfPlay"):
+    if name in ("MCTS", "MCTSNode", "self_play_game", "parallel_self_play", "InterruptedWithResults", "SelfPlay"):
         from . import self_play
         return getattr(self_play, name)
     if name in ("SelfPlayEngine", "HashNetEvaluator", "TorchNetEvaluator", "CallbackEvaluator"):

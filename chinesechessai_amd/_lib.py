@@ -165,6 +165,7 @@ _SIGNATURES = {
     "xq_engine_read_leaves": (C.c_int, [C.c_void_p] * 6),
     "xq_engine_write_priors": (C.c_int, [C.c_void_p] * 3),
     "xq_engine_read_root_visits": (C.c_int, [C.c_void_p] * 4),
+    "xq_engine_read_tree": (C.c_int, [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 8),
     "xq_engine_read_games": (C.c_int, [C.c_void_p] * 8),
     "xq_engine_read_samples": (C.c_int, [C.c_void_p] * 9),
     "xq_engine_pack_samples": (C.c_int, [C.c_void_p, C.c_void_p]),

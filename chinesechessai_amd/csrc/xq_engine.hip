@@ -2898,6 +2898,30 @@ extern "C" int xq_engine_read_root_visits(xq_engine *e, uint16_t *moves, int32_t
     return 0;
 }
 
+// the search tree of one game as it stands (after xq_engine_end_search: the finished tree of the ply): the node arena's
+// slices, node by node in creation order - MCTSNode's fields (self_play.py:19-28), children = [first, first + n_child)
+extern "C" int xq_engine_read_tree(xq_engine *e, int game, int cap, int32_t *n_nodes, int32_t *root, uint32_t *visit_count,
+                                   double *value_sum, float *prior, uint16_t *move, uint16_t *first_child, uint8_t *n_child)
+{
+    if (!e || !n_nodes || !root) return fail(XQ_E_INVALID, "null argument");
+    if (game < 0 || game >= e->E.G || cap < 0) return fail(XQ_E_INVALID, "xq_engine_read_tree: game out of range");
+    HIPCHK(hipSetDevice(e->cfg.device));
+    uint32_t nn = 0; uint16_t rt = 0;
+    HIPCHK(hipMemcpyAsync(&nn, e->E.n_nodes + game, 4, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpyAsync(&rt, e->E.root_node + game, 2, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    *n_nodes = (int32_t)nn; *root = (int32_t)rt;
+    const size_t n = nn < (uint32_t)cap ? nn : (size_t)cap, off = (size_t)game * e->E.ncap;
+    if (n && visit_count) HIPCHK(hipMemcpyAsync(visit_count, e->E.nN + off, n * 4, hipMemcpyDeviceToHost, e->stream));
+    if (n && value_sum) HIPCHK(hipMemcpyAsync(value_sum, e->E.nW + off, n * 8, hipMemcpyDeviceToHost, e->stream));
+    if (n && prior) HIPCHK(hipMemcpyAsync(prior, e->E.nP + off, n * 4, hipMemcpyDeviceToHost, e->stream));
+    if (n && move) HIPCHK(hipMemcpyAsync(move, e->E.nMove + off, n * 2, hipMemcpyDeviceToHost, e->stream));
+    if (n && first_child) HIPCHK(hipMemcpyAsync(first_child, e->E.nFirst + off, n * 2, hipMemcpyDeviceToHost, e->stream));
+    if (n && n_child) HIPCHK(hipMemcpyAsync(n_child, e->E.nNc + off, n, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return 0;
+}
+
 extern "C" int xq_engine_read_games(xq_engine *e, int32_t *winner, int32_t *reason, int32_t *reason_side,
                                     int32_t *reason_count, int32_t *n_plies, int32_t *n_samples, int32_t *error)
 {

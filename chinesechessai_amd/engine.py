@@ -412,6 +412,20 @@ class SelfPlayEngine:
         _lib.check(self.L.xq_engine_read_root_visits(self.h, _lib.ptr(moves), _lib.ptr(visits), _lib.ptr(n)))
         return moves, visits, n
 
+    def read_tree(self, game=0):
+        """The search tree of `game` as it stands (after search(): the finished tree of the ply), node by node in creation
+        order: dict of arrays visit_count, value_sum, prior, move, first_child, n_child (+ "root": the root's index) -
+        MCTSNode's fields, self_play.py:19-28; a node's children are [first_child, first_child + n_child)."""
+        nn, root = np.zeros(1, np.int32), np.zeros(1, np.int32)
+        _lib.check(self.L.xq_engine_read_tree(self.h, int(game), 0, _lib.ptr(nn), _lib.ptr(root), *([None] * 6)))
+        n = int(nn[0])
+        t = {"visit_count": np.zeros(n, np.uint32), "value_sum": np.zeros(n, np.float64), "prior": np.zeros(n, np.float32),
+             "move": np.zeros(n, np.uint16), "first_child": np.zeros(n, np.uint16), "n_child": np.zeros(n, np.uint8)}
+        _lib.check(self.L.xq_engine_read_tree(self.h, int(game), n, _lib.ptr(nn), _lib.ptr(root),
+                                              *[_lib.ptr(t[k]) for k in ("visit_count", "value_sum", "prior", "move", "first_child", "n_child")]))
+        t["root"] = int(root[0])
+        return t
+
     def active_games(self):
         n = np.zeros(1, np.int32)
         _lib.check(self.L.xq_engine_active_games(self.h, _lib.ptr(n)))

@@ -1,4 +1,4 @@
-"""Host mirror of the reference's self_play.py: MCTS, self_play_game, parallel_self_play,
+"""Host mirror of the reference's self_play.py: MCTSNode, MCTS, self_play_game, parallel_self_play,
 InterruptedWithResults — same names, arguments, return types and error behaviour
 (SURVEY.md §8b), backed by the HIP engine (engine.py / libxq_hip.so).
 
@@ -6,6 +6,8 @@ InterruptedWithResults — same names, arguments, return types and error behavio
 `chinesechessai_amd.neural_network.ChessNet` living on the GPU takes the fast path
 (TorchNetEvaluator: planes written by the search kernel, logits consumed by the tree kernel).
 """
+import math
+
 import numpy as np
 
 from . import _lib
@@ -63,6 +65,65 @@ def _evaluator_for(network, fast=True, inference_dtype=None):
     return CallbackEvaluator(network)
 
 
+class MCTSNode:
+    """self_play.py:19-80 - a node of the search tree with the reference's attribute names: `parent`, `move`, `children`
+    ({move: MCTSNode} in legal-move order), `visit_count`, `value_sum`, `prior_prob`.  The engine keeps its trees in a
+    device arena (csrc/xq_engine.hip: nN / nW / nP / nMove, one wavefront per game); MCTS.search(..., return_root=True) and
+    MCTS.root hand out the finished tree of the last search as a host COPY made of these objects, so tools written against
+    the reference's nodes can walk it.  expand() / update() act on that copy only."""
+    __slots__ = ("parent", "move", "children", "visit_count", "value_sum", "prior_prob")
+
+    def __init__(self, parent=None, move=None, prior_prob=0):
+        self.parent, self.move, self.prior_prob = parent, move, prior_prob
+        self.children = {}
+        self.visit_count, self.value_sum = 0, 0
+
+    def value(self):                                            # :30-34
+        return self.value_sum / self.visit_count if self.visit_count else 0
+
+    def is_leaf(self):                                          # :36-38
+        return not self.children
+
+    def select_child(self, c_puct=1.5):
+        """(move, child) with the highest PUCT score, the first one on ties (:40-59).  prior_prob is an np.float32, so
+        NumPy rounds every step to float32 exactly as it does in the reference."""
+        best = (None, None)
+        top = -float("inf")
+        root_n = math.sqrt(self.visit_count)
+        for mv, ch in self.children.items():
+            u = ch.value() + c_puct * ch.prior_prob * root_n / (1 + ch.visit_count)
+            if u > top:
+                top, best = u, (mv, ch)
+        return best
+
+    def expand(self, move_probs):                               # :61-68: only moves that are not children yet
+        for mv, p in move_probs.items():
+            self.children.setdefault(mv, MCTSNode(self, mv, p))
+
+    def update(self, value):                                    # :70-80: the sign flips at every level up
+        node = self
+        while node is not None:
+            node.visit_count += 1
+            node.value_sum += value
+            value, node = -value, node.parent
+
+    @staticmethod
+    def from_arena(tree):
+        """the host copy of a device tree (SelfPlayEngine.read_tree)"""
+        n = len(tree["move"])
+        nodes = [MCTSNode() for _ in range(n)]
+        for i, nd in enumerate(nodes):
+            nd.visit_count = int(tree["visit_count"][i])
+            # (the reference's value_sum is the int 0 until the first update, a Python float afterwards)
+            nd.value_sum = float(tree["value_sum"][i]) if nd.visit_count else 0
+            f, c = int(tree["first_child"][i]), int(tree["n_child"][i])
+            for j in range(f, f + c):
+                ch = nodes[j]
+                ch.parent, ch.move, ch.prior_prob = nd, decode_move(int(tree["move"][j])), np.float32(tree["prior"][j])
+                nd.children[ch.move] = ch
+        return nodes[tree["root"]] if n else MCTSNode()
+
+
 class MCTS:
     """self_play.py:83-175.  search(env) returns {move: visit_count} over ALL root children in
     legal-move order (Appendix A13); the tree is rebuilt on every call (self_play.py:98)."""
@@ -77,7 +138,8 @@ class MCTS:
             self._engines[sims] = SelfPlayEngine(1, sims=sims)
         return self._engines[sims]
 
-    def search(self, env, num_simulations=None):
+    def search(self, env, num_simulations=None, return_root=False):
+        """{move: visit_count} (self_play.py:151-154); return_root=True: (that, the finished tree's root as an MCTSNode)"""
         if num_simulations is None:
             num_simulations = self.default_simulations
         eng = self._engine(num_simulations)
@@ -93,7 +155,16 @@ class MCTS:
         eng.set_roots(np.ascontiguousarray(env.board, dtype=np.int8).reshape(1, 90), st)
         eng.search(ev)
         moves, visits, n = eng.root_visits()
-        return {decode_move(moves[0, j]): int(visits[0, j]) for j in range(int(n[0]))}
+        self._last = eng
+        out = {decode_move(moves[0, j]): int(visits[0, j]) for j in range(int(n[0]))}
+        return (out, self.root) if return_root else out
+
+    @property
+    def root(self):
+        """the finished tree of the last search() as MCTSNode objects (a host copy of the device arena)"""
+        if getattr(self, "_last", None) is None:
+            raise RuntimeError("MCTS.root: no search has run yet")
+        return MCTSNode.from_arena(self._last.read_tree(0))
 
 
 def _play_batch(network, num_games, temperature, num_simulations, opponent_network, seeds=None, uniforms=None,

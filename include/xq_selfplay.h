@@ -229,6 +229,14 @@ int  xq_engine_write_priors(xq_engine *e, const float *priors_host /*[G][128]*/,
 /* root children after xq_engine_end_search */
 int  xq_engine_read_root_visits(xq_engine *e, uint16_t *moves_host /*[G][128]*/, int32_t *visits_host,
                                 int32_t *n_child_host);
+/* The search tree of one game as it stands - after xq_engine_end_search: the finished tree of the ply - node by node in
+ * creation order: the fields of the reference's MCTSNode (/root/reference/self_play.py:19-28: move, visit_count,
+ * value_sum, prior_prob; a node's children are the nodes [first_child, first_child + n_child) in legal-move order, its
+ * parent the node that lists it).  *root_host = the root's index (0 unless tree reuse kept a subtree).  Copies
+ * min(cap, *n_nodes_host) entries; any of the array pointers may be NULL. */
+int  xq_engine_read_tree(xq_engine *e, int game, int cap, int32_t *n_nodes_host, int32_t *root_host, uint32_t *visit_count_host,
+                         double *value_sum_host, float *prior_host, uint16_t *move_host, uint16_t *first_child_host,
+                         uint8_t *n_child_host);
 /* per-game outcome: winner (0 for None, self_play.py:259), reason code/side/count, plies, samples, error
  * (error 1 = np.random.choice would raise ValueError: NaN probabilities, sims <= leaf_batch) */
 int  xq_engine_read_games(xq_engine *e, int32_t *winner_host, int32_t *reason_host, int32_t *reason_side_host,

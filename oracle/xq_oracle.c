@@ -605,9 +605,9 @@ static void node_update(tree_t *t, int ni, double value)
     }
 }
 
-/* self_play.py:89-154 */
-int xqo_mcts_search(const xqo_env *env, int sims, const xqo_evaluator *ev,
-                    uint16_t *out_moves, int32_t *out_visits)
+/* self_play.py:89-154; `dump` (may be NULL): the finished tree, node by node in creation order (self_play.py:19-28) */
+static int mcts_search_impl(const xqo_env *env, int sims, const xqo_evaluator *ev,
+                            uint16_t *out_moves, int32_t *out_visits, const xqo_tree_dump *dump)
 {
     tree_t t = { 0, 0, 0 };
     int root = tree_new_node(&t, -1, 0, 0.0f);
@@ -677,8 +677,31 @@ int xqo_mcts_search(const xqo_env *env, int sims, const xqo_evaluator *ev,
             out_visits[i] = t.nodes[t.nodes[root].first_child + i].visit_count;
         }
     } else n = rc;
+    if (rc == 0 && dump) {
+        *dump->n_nodes = t.n;
+        for (int i = 0; i < t.n && i < dump->cap; i++) {
+            const node_t *nd = &t.nodes[i];
+            dump->parent[i] = nd->parent; dump->move[i] = (uint16_t)nd->move; dump->visit_count[i] = nd->visit_count;
+            dump->value_sum[i] = nd->value_sum; dump->prior[i] = nd->prior;
+            dump->first_child[i] = nd->first_child; dump->n_child[i] = nd->n_child;
+        }
+    }
     free(t.nodes); free(se); free(l_boards); free(l_moves); free(l_priors);
     return n;
+}
+
+int xqo_mcts_search(const xqo_env *env, int sims, const xqo_evaluator *ev,
+                    uint16_t *out_moves, int32_t *out_visits)
+{
+    return mcts_search_impl(env, sims, ev, out_moves, out_visits, 0);
+}
+
+/* the same search, and every MCTSNode of its tree (self_play.py:19-28: parent, move, visit_count, value_sum,
+ * prior_prob; children = [first_child, first_child + n_child) in legal-move order) */
+int xqo_mcts_search_tree(const xqo_env *env, int sims, const xqo_evaluator *ev,
+                         uint16_t *out_moves, int32_t *out_visits, const xqo_tree_dump *dump)
+{
+    return mcts_search_impl(env, sims, ev, out_moves, out_visits, dump);
 }
 
 /* ------------------------------------------------------------------ NumPy sampling restated */

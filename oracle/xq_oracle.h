@@ -84,6 +84,15 @@ int      xqo_check_draw_by_repetition(const xqo_env *e);                      /*
 
 /* ---- search ---- */
 /* returns number of root children; out_moves/out_visits in insertion (legal-move) order. */
+/* the finished search tree, node by node in creation order (node 0 = root); arrays of `cap` entries, *n_nodes = nodes made */
+typedef struct {
+    int cap;
+    int32_t *n_nodes;
+    int32_t *parent; uint16_t *move; int32_t *visit_count; double *value_sum; float *prior;
+    int32_t *first_child; int32_t *n_child;
+} xqo_tree_dump;
+int xqo_mcts_search_tree(const xqo_env *env, int sims, const xqo_evaluator *ev,
+                         uint16_t *out_moves, int32_t *out_visits, const xqo_tree_dump *dump);
 int xqo_mcts_search(const xqo_env *env, int sims, const xqo_evaluator *ev,
                     uint16_t *out_moves, int32_t *out_visits);
 /* PUCT score exactly as NumPy>=2 evaluates self_play.py:51-52 (float32, stepwise). */

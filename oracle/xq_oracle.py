@@ -51,6 +51,13 @@ class Evaluator(C.Structure):
     _fields_ = [("fn", EVAL_FN), ("ctx", C.c_void_p)]
 
 
+class TreeDump(C.Structure):
+    _fields_ = [("cap", C.c_int), ("n_nodes", C.POINTER(C.c_int32)),
+                ("parent", C.POINTER(C.c_int32)), ("move", C.POINTER(C.c_uint16)), ("visit_count", C.POINTER(C.c_int32)),
+                ("value_sum", C.POINTER(C.c_double)), ("prior", C.POINTER(C.c_float)),
+                ("first_child", C.POINTER(C.c_int32)), ("n_child", C.POINTER(C.c_int32))]
+
+
 class Game(C.Structure):
     _fields_ = [
         ("n_samples", C.c_int32), ("n_plies", C.c_int32), ("winner", C.c_int32),
@@ -104,6 +111,8 @@ def lib():
         L.xqo_position_change.restype = C.c_double
         L.xqo_mcts_search.argtypes = [C.POINTER(Env), C.c_int, C.POINTER(Evaluator),
                                       C.POINTER(C.c_uint16), C.POINTER(C.c_int32)]
+        L.xqo_mcts_search_tree.argtypes = [C.POINTER(Env), C.c_int, C.POINTER(Evaluator),
+                                           C.POINTER(C.c_uint16), C.POINTER(C.c_int32), C.POINTER(TreeDump)]
         L.xqo_puct_score.argtypes = [C.c_double, C.c_int, C.c_float, C.c_int]
         L.xqo_puct_score.restype = C.c_float
         L.xqo_mt_seed.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_int), C.c_uint32]
@@ -226,6 +235,25 @@ class OracleEnv:
         vs = (C.c_int32 * MAX_MOVES)()
         n = self._L.xqo_mcts_search(self.p, sims, C.byref(ev), mv, vs)
         return [int(mv[i]) for i in range(n)], [int(vs[i]) for i in range(n)]
+
+    def search_tree(self, sims, evaluator=None, cap=65536):
+        """the same search and every node of its tree in creation order (self_play.py:19-28): dict of arrays
+        parent, move, visit_count, value_sum, prior, first_child, n_child"""
+        ev = evaluator or hashnet_evaluator()
+        mv = (C.c_uint16 * MAX_MOVES)()
+        vs = (C.c_int32 * MAX_MOVES)()
+        a = {"parent": np.zeros(cap, np.int32), "move": np.zeros(cap, np.uint16), "visit_count": np.zeros(cap, np.int32),
+             "value_sum": np.zeros(cap, np.float64), "prior": np.zeros(cap, np.float32),
+             "first_child": np.zeros(cap, np.int32), "n_child": np.zeros(cap, np.int32)}
+        nn = C.c_int32(0)
+        d = TreeDump(cap, C.pointer(nn), *[a[k].ctypes.data_as(t) for k, t in (
+            ("parent", C.POINTER(C.c_int32)), ("move", C.POINTER(C.c_uint16)), ("visit_count", C.POINTER(C.c_int32)),
+            ("value_sum", C.POINTER(C.c_double)), ("prior", C.POINTER(C.c_float)),
+            ("first_child", C.POINTER(C.c_int32)), ("n_child", C.POINTER(C.c_int32)))])
+        n = self._L.xqo_mcts_search_tree(self.p, sims, C.byref(ev), mv, vs, C.byref(d))
+        if n < 0 or nn.value > cap:
+            raise RuntimeError("search_tree: rc %d, %d nodes (cap %d)" % (n, nn.value, cap))
+        return {k: v[:nn.value].copy() for k, v in a.items()}
 
 
 def self_play_game(seed, sims, temperature=1.0, max_moves=70, eval_red=None, eval_black=None,

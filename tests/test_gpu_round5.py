@@ -322,3 +322,97 @@ def test_eval_cache_suspends_itself_when_it_answers_nothing(L):
     eng.play(ev, seeds)
     assert eng.eval_cache and ev.eval_cache_suspended == 0 and ev.eval_cache_last[0] > 0.1 * ev.eval_cache_last[2]
     eng.close()
+
+
+def test_search_tree_equals_oracle_node_by_node(L):
+    """the whole search tree - every MCTSNode's move, visit_count, value_sum, prior_prob and child
+    range (self_play.py:19-28), not only the root's visit counts - equals the oracle's, bit for bit, on positions reached
+    by seeded random play, at 15 / 50 / 200 simulations; and MCTS.search(..., return_root=True) hands the same tree out
+    as MCTSNode objects whose select_child picks what the oracle's PUCT (pinned by the golden vectors) picks."""
+    from chinesechessai_amd import _lib
+    from chinesechessai_amd.engine import SelfPlayEngine, HashNetEvaluator
+    from chinesechessai_amd.self_play import MCTS, MCTSNode
+    from chinesechessai_amd import ChineseChess
+    from chinesechessai_amd.chess_env import decode_move
+    from oracle import xq_oracle as xo
+
+    rng = np.random.RandomState(20261005)
+    envs, lines = [], []
+    for k in range(12):
+        oe = xo.OracleEnv()
+        line = []
+        for _ in range(3 * k):
+            mv = oe.legal_moves()
+            if not mv or oe.e.winner != xo.WINNER_NONE:
+                break
+            m = int(mv[rng.randint(len(mv))])
+            line.append(m)
+            oe.make_move(m)
+        if oe.e.winner == xo.WINNER_NONE and oe.legal_moves():
+            envs.append(oe); lines.append(line)
+    n = len(envs)
+    assert n >= 10
+    boards = np.stack([np.array(oe.board(), dtype=np.int8).reshape(90) for oe in envs])
+    st = np.zeros((n, _lib.STATE_WORDS), np.int32)
+    for i, oe in enumerate(envs):
+        e = oe.e
+        st[i, _lib.S_PLAYER], st[i, _lib.S_MOVE_COUNT], st[i, _lib.S_WINNER] = e.current_player, e.move_count, _lib.WINNER_NONE
+        st[i, _lib.S_RED_KING], st[i, _lib.S_BLACK_KING], st[i, _lib.S_NO_CAPTURE] = e.red_king, e.black_king, e.no_capture_count
+    total = 0
+    for S in (15, 50, 200):
+        eng = SelfPlayEngine(n, sims=S)
+        ev = HashNetEvaluator()
+        ev.bind(eng)
+        eng.set_roots(boards, st)
+        eng.search(ev)
+        for i, oe in enumerate(envs):
+            ref = oe.search_tree(S)
+            got = eng.read_tree(i)
+            m = len(ref["move"])
+            assert got["root"] == 0 and len(got["move"]) == m, (S, i, len(got["move"]), m)
+            assert np.array_equal(got["visit_count"].astype(np.int64), ref["visit_count"]), (S, i)
+            assert np.array_equal(got["value_sum"].view(np.uint64), ref["value_sum"].view(np.uint64)), (S, i)
+            assert np.array_equal(got["prior"][1:].view(np.uint32), ref["prior"][1:].view(np.uint32)), (S, i)
+            assert np.array_equal(got["move"][1:], ref["move"][1:]), (S, i)
+            assert np.array_equal(got["n_child"].astype(np.int64), ref["n_child"]), (S, i)
+            exp = ref["n_child"] > 0
+            assert np.array_equal(got["first_child"].astype(np.int64)[exp], ref["first_child"][exp]), (S, i)
+            assert int(ref["visit_count"][0]) == S
+            total += m
+        eng.close()
+    print("search trees compared node by node with the oracle's: %d positions x 3 simulation counts, %d nodes" % (n, total))
+
+    # the mirror's MCTSNode view of the same arena
+    env = ChineseChess()
+    for m in lines[4]:
+        env.make_move(decode_move(m))
+    mcts = MCTS(HashNetEvaluator(), num_simulations=50)
+    visits, root = mcts.search(env, return_root=True)
+    ref = envs[4].search_tree(50)
+    assert isinstance(root, MCTSNode) and root.parent is None and root.move is None and root.visit_count == 50
+    assert list(root.children) == list(visits) and [c.visit_count for c in root.children.values()] == list(visits.values())
+    f = int(ref["first_child"][0])
+    for j, (mv, ch) in enumerate(root.children.items()):
+        assert ch.parent is root and ch.move == mv == decode_move(int(ref["move"][f + j]))
+        assert isinstance(ch.prior_prob, np.float32) and ch.prior_prob == ref["prior"][f + j]
+        assert ch.value_sum == ref["value_sum"][f + j] and ch.is_leaf() == (ref["n_child"][f + j] == 0)
+    # select_child: the oracle's float32-stepwise PUCT (pinned by the reference's golden search vectors) picks the same child
+    lib = xo.lib()
+    def walk(node, idx, depth=0):
+        if node.is_leaf():
+            return 0
+        fc, nc = int(ref["first_child"][idx]), int(ref["n_child"][idx])
+        scores = [lib.xqo_puct_score(float(ref["value_sum"][fc + j]), int(ref["visit_count"][fc + j]), float(ref["prior"][fc + j]),
+                                     int(ref["visit_count"][idx])) for j in range(nc)]
+        best = int(np.argmax(np.array(scores, dtype=np.float32)))            # (argmax: the first maximum, like the strict '>')
+        mv, ch = node.select_child()
+        assert mv == decode_move(int(ref["move"][fc + best])) and ch is list(node.children.values())[best], (depth, idx)
+        return 1 + sum(walk(c, fc + j, depth + 1) for j, c in enumerate(node.children.values()) if not c.is_leaf())
+    assert walk(root, 0) >= 5
+    # expand() adds only missing moves; update() flips the sign on the way up (host copy only)
+    leaf = next(c for c in root.children.values() if c.is_leaf())
+    n0, w0, rn, rw = leaf.visit_count, leaf.value_sum, root.visit_count, root.value_sum
+    leaf.expand({(0, 0, 1, 0): np.float32(0.5)}); leaf.expand({(0, 0, 1, 0): np.float32(0.25), (0, 0, 2, 0): np.float32(0.25)})
+    assert [c.prior_prob for c in leaf.children.values()] == [np.float32(0.5), np.float32(0.25)]
+    leaf.update(0.5)
+    assert (leaf.visit_count, leaf.value_sum, root.visit_count, root.value_sum) == (n0 + 1, w0 + 0.5, rn + 1, rw - 0.5)
