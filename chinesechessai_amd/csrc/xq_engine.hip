@@ -133,6 +133,12 @@ __device__ __forceinline__ void ec_st(uint32_t *p, uint32_t v) { __hip_atomic_st
 __device__ __forceinline__ unsigned long long ec_ld64(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void ec_st64(unsigned long long *p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ float ec_ldf(const float *p) { return __uint_as_float(ec_ld(reinterpret_cast<const uint32_t *>(p))); }
+// key and priors of an entry that was FILLED IN AN EARLIER LAUNCH (state word: filled < this launch's number): ordinary
+// cached loads - a kernel boundary lies between the stores and these reads, and nobody refills an entry that is still
+// valid - so a position many games hold at once is served by the L2s, not by one memory channel.  (Measured: no
+// difference on BASELINE C3, where hits are spread; verify mode over whole games: 0 mismatches in 46 M leaves.)
+__device__ __forceinline__ uint32_t ec_old(const uint32_t *p) { return *p; }
+__device__ __forceinline__ float ec_oldf(const float *p) { return *p; }
 // a 64-bit value of the first active lane, wave-uniform.  (__builtin_amdgcn_readfirstlane returns int: without the casts the
 // low half is SIGN-extended into the high one - a state word that ends in 0xffffffff then reads as all ones.)
 __device__ __forceinline__ unsigned long long uni64(unsigned long long v)
@@ -394,9 +400,9 @@ __device__ void consume_eval(const Eng &E, int g, int slot, WaveLds &L, const Tr
     const int ec = E.ec_on ? uni(E.leaf_ec[slot]) : -1;      // evaluation cache: >= 0 it answers, <= -2 this wave fills entry -(ec + 2)
     if (ec >= 0 && E.ec_on == 1) {
         const float *pr = E.ec_prior + (size_t)ec * MAXM;
-        if (lane < n) p0 = ec_ldf(pr + lane);
-        if (lane + 64 < n) p1 = ec_ldf(pr + lane + 64);
-        v = (double)__uint_as_float(ec_ld(&E.ec_key[(size_t)ec * 16 + 14]));
+        if (lane < n) p0 = ec_oldf(pr + lane);
+        if (lane + 64 < n) p1 = ec_oldf(pr + lane + 64);
+        v = (double)__uint_as_float(ec_old(&E.ec_key[(size_t)ec * 16 + 14]));
         if (lane == 0) E.ec_stats[slot] += 1u;
     } else if (eval_kind == XQ_EVAL_PRIORS) {
         const float *pr = reinterpret_cast<const float *>(ev_a) + (size_t)slot * MAXM;
@@ -434,9 +440,9 @@ __device__ void consume_eval(const Eng &E, int g, int slot, WaveLds &L, const Tr
             if (lane == 0) E.ec_stats[E.ec_stat_stride + slot] += 1u;
         } else if (ec >= 0) {                                 // verify mode
             const float *pr = E.ec_prior + (size_t)ec * MAXM;
-            const bool bad = (lane < n && __float_as_uint(ec_ldf(pr + lane)) != __float_as_uint(p0)) ||
-                             (lane + 64 < n && __float_as_uint(ec_ldf(pr + lane + 64)) != __float_as_uint(p1)) ||
-                             ec_ld(&E.ec_key[(size_t)ec * 16 + 14]) != __float_as_uint((float)v) || ec_ld(&E.ec_key[(size_t)ec * 16 + 13]) != (uint32_t)n;
+            const bool bad = (lane < n && __float_as_uint(ec_oldf(pr + lane)) != __float_as_uint(p0)) ||
+                             (lane + 64 < n && __float_as_uint(ec_oldf(pr + lane + 64)) != __float_as_uint(p1)) ||
+                             ec_old(&E.ec_key[(size_t)ec * 16 + 14]) != __float_as_uint((float)v) || ec_old(&E.ec_key[(size_t)ec * 16 + 13]) != (uint32_t)n;
             const bool any = __ballot(bad) != 0ull;
             if (lane == 0) { E.ec_stats[slot] += 1u; if (any) E.ec_stats[2 * E.ec_stat_stride + slot] += 1u; }
         }
@@ -656,7 +662,7 @@ __device__ __forceinline__ int eval_cache_probe(const Eng &E, uint64_t h, uint32
             return old == st ? -(int)pos - 2 : -1;              // (lost the race: most likely to a wave with this very position)
         }
         if (filled >= seq) return -1;                           // reserved or filled in this launch: contents not visible yet
-        const uint32_t theirs = lane < 13 ? ec_ld(&E.ec_key[(size_t)pos * 16 + lane]) : 0u;
+        const uint32_t theirs = lane < 13 ? ec_old(&E.ec_key[(size_t)pos * 16 + lane]) : 0u;
         const uint32_t mine = lane < 12 ? my_dword : (uint32_t)(side + 2);
         if (__ballot(lane < 13 && theirs != mine) == 0ull) {
             return (int)pos;
@@ -1049,9 +1055,9 @@ __device__ void search_round_one(const Eng &E, WaveLds &L, int round, int batch_
         if (p_ec >= 0 && E.ec_on == 1) {
             // the evaluation cache holds this position's priors and value (the same bits the network would return)
             const float *pr = E.ec_prior + (size_t)p_ec * MAXM;
-            if (lane < n) p0 = ec_ldf(pr + lane);
-            if (lane + 64 < n) p1 = ec_ldf(pr + lane + 64);
-            v = (double)__uint_as_float(ec_ld(&E.ec_key[(size_t)p_ec * 16 + 14]));
+            if (lane < n) p0 = ec_oldf(pr + lane);
+            if (lane + 64 < n) p1 = ec_oldf(pr + lane + 64);
+            v = (double)__uint_as_float(ec_old(&E.ec_key[(size_t)p_ec * 16 + 14]));
             if (lane == 0) E.ec_stats[slot] += 1u;
         } else if (eval_kind == XQ_EVAL_PRIORS) {
             const float *pr = reinterpret_cast<const float *>(ev_a) + (size_t)slot * MAXM;
@@ -1090,9 +1096,9 @@ __device__ void search_round_one(const Eng &E, WaveLds &L, int round, int batch_
             } else if (p_ec >= 0) {
                 // verify mode (ec_on == 2): the leaf was evaluated although the cache holds its position - they must agree
                 const float *pr = E.ec_prior + (size_t)p_ec * MAXM;
-                const bool bad = (lane < n && __float_as_uint(ec_ldf(pr + lane)) != __float_as_uint(p0)) ||
-                                 (lane + 64 < n && __float_as_uint(ec_ldf(pr + lane + 64)) != __float_as_uint(p1)) ||
-                                 ec_ld(&E.ec_key[(size_t)p_ec * 16 + 14]) != __float_as_uint((float)v) || ec_ld(&E.ec_key[(size_t)p_ec * 16 + 13]) != (uint32_t)n;
+                const bool bad = (lane < n && __float_as_uint(ec_oldf(pr + lane)) != __float_as_uint(p0)) ||
+                                 (lane + 64 < n && __float_as_uint(ec_oldf(pr + lane + 64)) != __float_as_uint(p1)) ||
+                                 ec_old(&E.ec_key[(size_t)p_ec * 16 + 14]) != __float_as_uint((float)v) || ec_old(&E.ec_key[(size_t)p_ec * 16 + 13]) != (uint32_t)n;
                 const bool any = __ballot(bad) != 0ull;
                 if (lane == 0) { E.ec_stats[slot] += 1u; if (any) E.ec_stats[2 * E.ec_stat_stride + slot] += 1u; }
             }
