@@ -416,3 +416,52 @@ def test_search_tree_equals_oracle_node_by_node(L):
     assert [c.prior_prob for c in leaf.children.values()] == [np.float32(0.5), np.float32(0.25)]
     leaf.update(0.5)
     assert (leaf.visit_count, leaf.value_sum, root.visit_count, root.value_sum) == (n0 + 1, w0 + 0.5, rn + 1, rw - 0.5)
+
+
+@pytest.mark.parametrize("ext", ["noise+schedule", "virtual_loss", "tree_reuse", "all"])
+def test_eval_cache_is_result_identical_under_the_search_extensions(L, ext):
+    """The evaluation cache is keyed by the position alone, so it must not care how the tree above a leaf is searched: under
+    Dirichlet root noise + a per-ply temperature schedule (BASELINE C5's settings), virtual loss (8 pending leaves per game
+    and round: the generic kernel path, 8 slots per game), tree reuse, and all of them together, 256 games x S = 48 with the
+    mate-line network give the same records with the cache as without it; the cache must really answer; and its verify
+    mode finds every answer equal to a fresh evaluation."""
+    import torch
+    from chinesechessai_amd import distributed as xd
+    from chinesechessai_amd.engine import SelfPlayEngine, TorchNetEvaluator
+    G, S = 256, 48
+    net = _mate_line_net(2, 11)
+    seeds = (np.arange(G, dtype=np.uint32) * 7 + 3).astype(np.uint32)
+    block = 70 * xd.RECORD_BYTES
+
+    def run(cache):
+        ev = TorchNetEvaluator(net, leaf_dedupe=True, eval_cache=cache)
+        eng = SelfPlayEngine(G, sims=S, planes_format=ev.planes_format, max_moves=24)
+        sched = None
+        if ext in ("noise+schedule", "all"):
+            eng.set_root_noise(0.3, 0.25, seed=99)
+            sched = lambda ply: 1.0 if ply < 10 else 0.001
+        if ext in ("tree_reuse", "all"):
+            eng.set_tree_reuse(True)
+        if ext in ("virtual_loss", "all"):
+            eng.set_virtual_loss(True)
+        eng.play(ev, seeds, read=False, temperature_schedule=sched)
+        t = torch.zeros(G * block, dtype=torch.uint8, device="cuda")
+        eng.pack_samples(t.data_ptr())
+        out = eng.read_game_outcomes()
+        stats = eng.eval_cache_stats() if cache else (0, 0, 0)
+        eng.close()
+        return xd.records_to_numpy(t).reshape(G, 70), out, stats
+
+    ref, ref_out, _ = run(False)
+    assert int(ref_out["error"].sum()) == 0
+    rec, out, (hits, fills, _) = run("on")
+    for k in ("winner", "reason", "reason_side", "reason_count", "n_plies", "n_samples", "error"):
+        assert np.array_equal(out[k], ref_out[k]), (ext, k)
+    for g in range(G):
+        _same_game(rec[g], ref[g], (ext, g))
+    assert hits > 0 and fills > 0, (ext, hits, fills)
+    rec_v, out_v, (compared, fills_v, bad) = run("verify")
+    assert bad == 0 and compared > 0, (ext, compared, bad)
+    for g in range(G):
+        _same_game(rec_v[g], ref[g], (ext, "verify", g))
+    print("eval cache under %s: %d hits, %d fills; verify mode compared %d answers, 0 mismatches" % (ext, hits, fills, compared))
