@@ -20,7 +20,9 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 #include "mfma_shape_clock_body.inc"
 
 // V: 0 = R16, 1 = R32 (operands stay in registers), 2 = L16, 3 = L32 (the other operand set re-read from LDS under the MFMAs:
-// two K = 32 steps per loop pass).  The loops are asm statements with fixed registers (gen_mfma_shape_clock.py).
+// two K = 32 steps per loop pass); 4..8 = L16 with 1, 2, 3, 4, 6 x 16 idle cycles behind every 12 MFMAs (the duty sweep: how the
+// sustained rate moves with the matrix pipe's share of the cycles).  The loops are asm statements with fixed registers
+// (gen_mfma_shape_clock.py).
 template <int V>
 __global__ __launch_bounds__(256) void k_probe(const uint4 *src, float *sink, unsigned long long *clk, int passes)
 {
@@ -37,6 +39,11 @@ __global__ __launch_bounds__(256) void k_probe(const uint4 *src, float *sink, un
     if (V == 1) asm volatile(PROBE_BODY_R32 : [o] "=v"(o) : [a0] "v"(a0), [a1] "v"(a1), [n] "s"(passes) : PROBE_CLOBBERS);
     if (V == 2) asm volatile(PROBE_BODY_L16 : [o] "=v"(o) : [a0] "v"(a0), [a1] "v"(a1), [n] "s"(passes) : PROBE_CLOBBERS);
     if (V == 3) asm volatile(PROBE_BODY_L32 : [o] "=v"(o) : [a0] "v"(a0), [a1] "v"(a1), [n] "s"(passes) : PROBE_CLOBBERS);
+    if (V == 4) asm volatile(PROBE_BODY_L16_I1 : [o] "=v"(o) : [a0] "v"(a0), [a1] "v"(a1), [n] "s"(passes) : PROBE_CLOBBERS);
+    if (V == 5) asm volatile(PROBE_BODY_L16_I2 : [o] "=v"(o) : [a0] "v"(a0), [a1] "v"(a1), [n] "s"(passes) : PROBE_CLOBBERS);
+    if (V == 6) asm volatile(PROBE_BODY_L16_I3 : [o] "=v"(o) : [a0] "v"(a0), [a1] "v"(a1), [n] "s"(passes) : PROBE_CLOBBERS);
+    if (V == 7) asm volatile(PROBE_BODY_L16_I4 : [o] "=v"(o) : [a0] "v"(a0), [a1] "v"(a1), [n] "s"(passes) : PROBE_CLOBBERS);
+    if (V == 8) asm volatile(PROBE_BODY_L16_I6 : [o] "=v"(o) : [a0] "v"(a0), [a1] "v"(a1), [n] "s"(passes) : PROBE_CLOBBERS);
     if (stamp) {
         const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
         atomicAdd(&clk[0], c1 - c0);
@@ -64,15 +71,19 @@ int main(int argc, char **argv)
     CHECK(hipMalloc(&src, n16 * 16)); CHECK(hipMalloc(&sink, WG * 256 * 4)); CHECK(hipMalloc(&clk, 16));
     CHECK(hipMemcpy(src, h.data(), n16 * 16, hipMemcpyHostToDevice));
     const size_t ldsb = n16 * 16;
-    void (*ks[4])(const uint4 *, float *, unsigned long long *, int) = {k_probe<0>, k_probe<1>, k_probe<2>, k_probe<3>};
-    const char *names[4] = {"16x16x32, registers only", "32x32x16, registers only", "16x16x32 + 14 ds_read_b128 per K=32", "32x32x16 + 14 ds_read_b128 per K=32"};
-    for (int c = 0; c < 4; c++) CHECK(hipFuncSetAttribute((const void *)ks[c], hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
+    const int NV = 9;
+    void (*ks[NV])(const uint4 *, float *, unsigned long long *, int) = {k_probe<0>, k_probe<1>, k_probe<2>, k_probe<3>, k_probe<4>, k_probe<5>,
+                                                                        k_probe<6>, k_probe<7>, k_probe<8>};
+    const char *names[NV] = {"16x16x32, registers only", "32x32x16, registers only", "16x16x32 + 14 ds_read_b128 per K=32", "32x32x16 + 14 ds_read_b128 per K=32",
+                             "16x16x32 + LDS, 16 idle / 12 MFMAs", "16x16x32 + LDS, 32 idle / 12 MFMAs", "16x16x32 + LDS, 48 idle / 12 MFMAs",
+                             "16x16x32 + LDS, 64 idle / 12 MFMAs", "16x16x32 + LDS, 96 idle / 12 MFMAs"};
+    for (int c = 0; c < NV; c++) CHECK(hipFuncSetAttribute((const void *)ks[c], hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
     const double flop_it = 1024.0 * 48 * 16384;                  // per loop iteration over the chip: 1,024 waves x 48 MFMAs' worth
     const int iters = (int)(seconds * 2.2e15 / flop_it) & ~1;
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
     printf("iterations per launch %d (%.1f TFLOP per launch)\n", iters, iters * flop_it / 1e12);
     for (int r = 0; r < reps + 1; r++)
-        for (int c = 0; c < 4; c++) {
+        for (int c = 0; c < NV; c++) {
             CHECK(hipMemset(clk, 0, 16));
             CHECK(hipEventRecord(e0));
             hipLaunchKernelGGL(ks[c], dim3(WG), dim3(256), ldsb, 0, src, sink, clk, c >= 2 ? iters / 2 : iters);
