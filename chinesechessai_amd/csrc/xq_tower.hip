@@ -867,6 +867,8 @@ static int launch_tower(void *stream, const void *planes, const void *w1, const 
     else if (STAMP && v == 69) XQ_TOWER_LAUNCH((k_tower1wa<true, 9>), grid4, 256, LDS_BYTES1WA);
     else if (STAMP && v == 70) XQ_TOWER_LAUNCH((k_tower1wa<true, 10>), grid4, 256, LDS_BYTES1WA);
     else if (STAMP && v == 71) XQ_TOWER_LAUNCH((k_tower1wa<true, 11>), grid4, 256, LDS_BYTES1WA);
+    else if (STAMP && v == 72) XQ_TOWER_LAUNCH((k_tower1wa<true, 12>), grid4, 256, LDS_BYTES1WA);    // work-removal probes: 46 / 44 of the 48 MFMAs
+    else if (STAMP && v == 73) XQ_TOWER_LAUNCH((k_tower1wa<true, 13>), grid4, 256, LDS_BYTES1WA);    //   per K-step (pixel tile 5 without 2 / 4 channel tiles)
     else if (STAMP && v == 51) XQ_TOWER_LAUNCH((k_tower1w<true, 1>), grid4, 256, LDS_BYTES1W);       // ... no stage barriers (wrong results)
     else if (STAMP && v == 52) XQ_TOWER_LAUNCH((k_tower1w<true, 3>), grid4, 256, LDS_BYTES1W);       // ... no barriers, no vmcnt waits
     else if (STAMP && v == 53) XQ_TOWER_LAUNCH((k_tower1w<true, 7>), grid4, 256, LDS_BYTES1W);       // ... and no weight DMA

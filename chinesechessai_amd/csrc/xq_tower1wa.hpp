@@ -375,6 +375,8 @@ __global__ __launch_bounds__(256, 1) void k_tower1wa(TowerArgs A)
         else if constexpr (ABL == 9) XQ_1WA_RUN_ABL(9);
         else if constexpr (ABL == 10) XQ_1WA_RUN_ABL(10);
         else if constexpr (ABL == 11) XQ_1WA_RUN_ABL(11);
+        else if constexpr (ABL == 12) XQ_1WA_RUN_ABL(12);
+        else if constexpr (ABL == 13) XQ_1WA_RUN_ABL(13);
         else
 #endif
         if constexpr (STAMP)

@@ -139,6 +139,11 @@ class Emitter:
                 return "v[%d:%d]" % (V_SEL + 4 * o, V_SEL + 4 * o + 3)
             n = int(x[2:])
             return "v[%d:%d]" % (V_XF + 4 * n, V_XF + 4 * n + 3)
+        # work-removal probes (timing only): "drop2" / "drop4" leave out the convolution MFMAs of 2 / 4 of the 8 channel tiles of
+        # pixel tile 5 - 46 / 44 MFMAs per K-step instead of 48: what shedding the padding rows' work would be worth under the
+        # power cap
+        if want[0] != "skip" and tile % 6 == 5 and (("drop2" in ABL and tile // 6 >= 6) or ("drop4" in ABL and tile // 6 >= 4)):
+            return
         t = 4 * tile
         c = A_BIAS + 4 * (tile // 6) if first else t
         self.add("v_mfma_f32_16x16x32_bf16 a[%d:%d], %s, %s, a[%d:%d]" % (t, t + 3, reg(a), reg(b), c, c + 3), "mfma",
@@ -1292,7 +1297,7 @@ def generate():
 
 
 ABLATIONS = [("noaccread",), ("nostore",), ("nodrain",), ("nodma",), ("nobar",), ("nodrain", "nodma", "nobar"),
-             ("valu2",), ("valu3",), ("valu4",), ("valu3", "dma35"), ("valu4", "dma35")]
+             ("valu2",), ("valu3",), ("valu4",), ("valu3", "dma35"), ("valu4", "dma35"), ("drop2",), ("drop4",)]
 
 
 def main():

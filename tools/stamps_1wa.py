@@ -45,7 +45,8 @@ nwg = (G + 3) // 4
 stamps = torch.zeros(((G + 1) // 2) * 64, dtype=torch.int64, device="cuda")
 ABL_NAMES = {61: "drains read VGPRs, not accumulators", 62: "no stores", 63: "no drain", 64: "no weight DMA", 65: "no barriers",
              66: "no drain, DMA, barriers", 67: "Winograd probe: 2 extra VALU per MFMA", 68: "3 extra VALU per MFMA", 69: "4 extra VALU per MFMA",
-             70: "3 extra VALU per MFMA, 3.5 x the weight DMA", 71: "4 extra VALU per MFMA, 3.5 x the weight DMA"}
+             70: "3 extra VALU per MFMA, 3.5 x the weight DMA", 71: "4 extra VALU per MFMA, 3.5 x the weight DMA",
+             72: "46 of the 48 MFMAs per K-step (pixel tile 5 without 2 of its 8 channel tiles)", 73: "44 of the 48 MFMAs per K-step"}
 extra = [int(v) for v in os.environ.get("XQ_1WA_ABL", "").split(",") if v]
 for variant in [60] + extra + [39]:
     L.xq_tower_set_variant(variant)
